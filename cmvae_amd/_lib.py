@@ -1,0 +1,69 @@
+"""ctypes loader for libcmvae_hip.so (the C-ABI declared in include/cmvae_abi.h).
+
+The product path has no fallback: if the library is missing or a symbol is absent this
+module raises at import time.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcmvae_hip.so')
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+
+
+class CausalDesc(ctypes.Structure):
+    """struct cmvae_causal (include/cmvae_abi.h)."""
+    _fields_ = [('linear', ctypes.c_int32), ('W', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p)]
+
+
+_PC = ctypes.POINTER(CausalDesc)
+
+# name -> (restype, argtypes); must list every symbol of include/cmvae_abi.h
+SIGNATURES = {
+    'cmvae_last_error': (ctypes.c_char_p, []),
+    'cmvae_abi_version': (c_int, []),
+    'cmvae_causal_rows': (c_int, [c_void_p, c_int, _PC, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_gram_inverse': (c_int, [c_void_p, c_float, c_int, _PC, c_void_p, c_void_p]),
+    'cmvae_unsup_prior_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cmvae_unsup_prior': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, _PC, c_int, c_int, c_float,
+                                  c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_semi_prior_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'cmvae_semi_prior': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, _PC, c_int, c_float,
+                                 c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_posterior_argmax': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
+    'cmvae_mixture_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cmvae_mixture_loglik_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cmvae_mixture_loglik_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'cmvae_reparam_logq_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'cmvae_reparam_logq_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
+    'cmvae_expm_trace': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'cmvae_amd: %s not found. Build it with `make -C cmvae_amd/csrc` (or '
+            '`python -c "import __graft_entry__ as g; g.build()"`). There is no fallback path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib.cmvae_last_error()
+        raise RuntimeError('%s failed: %s' % (what or 'cmvae call', msg.decode() if msg else 'unknown error'))

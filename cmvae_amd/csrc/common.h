@@ -1,0 +1,31 @@
+// Shared host/device helpers for libcmvae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/cmvae_abi.h"
+
+namespace cmvae {
+
+constexpr int D = CMVAE_D;
+constexpr int M1 = CMVAE_M1;
+constexpr int HID = D * M1;                      // 2048 hidden units of the NOTEARS-MLP
+constexpr float LOG_NORM = -0.91893853320467274178f;   // -0.5*log(2*pi)
+
+int set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error("%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+}  // namespace cmvae
+
+#define CMVAE_REQUIRE(cond, ...) \
+    do { if (!(cond)) return cmvae::set_error(__VA_ARGS__); } while (0)

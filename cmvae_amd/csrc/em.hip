@@ -1,0 +1,876 @@
+// Per-episode latent GMM EM (unsupervised + semi-supervised), the causal prior term, the
+// batched (I + C C^T)^-1, the mixture log-likelihood (fwd/bwd) and the few-shot posterior.
+// gfx950 / wave64.  All episodes of the meta-batch run in one launch (grid.y = episode).
+//
+// Layout in HBM: z [B,N,64] row-major fp32 (256-B rows); mixture parameters
+// mu/logvar [B,K,64], pi/tau/logw [B,K].  Per-block partial sums
+// part_N [B,nblk,32], part_S1/part_S2 [B,nblk,K,64] are reduced in a fixed order by the
+// finalize kernels (no float atomics: results are run-to-run reproducible).
+#include "common.h"
+#include <type_traits>
+
+namespace cmvae {
+
+// ------------------------------------------------------------------ small math helpers
+// expm1 accurate to ~2e-7 relative without the cost of ocml's expm1f.
+__device__ __forceinline__ float expm1_fast(float x) {
+    // Horner, degree 8 on [-0.35, 0]; exp(x)-1 below that (|result| >= 0.29)
+    float p = 1.f / 40320.f;
+    p = fmaf(p, x, 1.f / 5040.f);
+    p = fmaf(p, x, 1.f / 720.f);
+    p = fmaf(p, x, 1.f / 120.f);
+    p = fmaf(p, x, 1.f / 24.f);
+    p = fmaf(p, x, 1.f / 6.f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.f);
+    p = p * x;
+    float e = __expf(x) - 1.f;
+    return x > -0.35f ? p : e;
+}
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1_fast(x); }
+
+// ------------------------------------------------------------------ causal residual of ONE row
+// xs[64] (LDS) -> es[64] (LDS) = xs - mask(xs).  Whole 256-thread block participates;
+// caller must __syncthreads() before reading es.
+__device__ __forceinline__ void causal_row_256(const float* xs, float* es, const cmvae_causal& c) {
+    const int tid = threadIdx.x;
+    if (c.linear) {
+        if (tid < D) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < D; ++i) acc = fmaf(xs[i], c.W[i * D + tid], acc);
+            es[tid] = xs[tid] - acc;
+        }
+        return;
+    }
+    const int lane = tid & 63, w = tid >> 6;
+    const int q = lane & 15;     // which float4 of the 64-wide fc1 row
+    const int sub = lane >> 4;   // which of the 4 hidden units of a 1-KiB packet
+    const float4 xv = reinterpret_cast<const float4*>(xs)[q];
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = 16 * w + jj;
+        float acc = 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int u = 32 * j + 4 * it + sub;
+            const float4 wv = reinterpret_cast<const float4*>(c.W + (size_t)u * D)[q];
+            float p = wv.x * xv.x;
+            p = fmaf(wv.y, xv.y, p);
+            p = fmaf(wv.z, xv.z, p);
+            p = fmaf(wv.w, xv.w, p);
+            p += __shfl_xor(p, 1);
+            p += __shfl_xor(p, 2);
+            p += __shfl_xor(p, 4);
+            p += __shfl_xor(p, 8);
+            acc = fmaf(elu_f(p + c.b1[u]), c.w2[u], acc);
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (lane == 0) es[j] = xs[j] - (acc + c.b2[j]);
+    }
+}
+
+// sum over 64 values held one per thread of the first wave... generic block reduce of 64 floats in LDS
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// glp(eps, log tau) for a row held in LDS: sum_j -0.5*(eps_j - lt)^2 + c   (wave 0 only)
+__device__ __forceinline__ float prior_term_wave0(const float* es, float log_tau) {
+    const int lane = threadIdx.x & 63;
+    float d = es[lane] - log_tau;
+    float v = -0.5f * (d * d) + LOG_NORM;
+    return wave_sum(v);
+}
+
+// ------------------------------------------------------------------ kernel: causal on rows
+__global__ __launch_bounds__(256) void causal_rows_kernel(const float* __restrict__ x, int rows, cmvae_causal c,
+                                                          const float* __restrict__ pi,
+                                                          const float* __restrict__ tau,
+                                                          float* __restrict__ eps, float* __restrict__ logw) {
+    __shared__ __align__(16) float xs[D];
+    __shared__ __align__(16) float es[D];
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        if (threadIdx.x < D) xs[threadIdx.x] = x[(size_t)r * D + threadIdx.x];
+        __syncthreads();
+        causal_row_256(xs, es, c);
+        __syncthreads();
+        if (threadIdx.x < D) {
+            if (eps) eps[(size_t)r * D + threadIdx.x] = es[threadIdx.x];
+            if (logw) {
+                float p = prior_term_wave0(es, logf(tau[r]));
+                if (threadIdx.x == 0) logw[r] = logf(pi[r]) + p;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ kernel: (I + C C^T)^-1
+// One block per matrix.  C row i = causal(s_i e_i).
+constexpr int CT_LD = 68;   // C^T leading dim (float4-aligned, conflict-free float4 reads)
+constexpr int MS_LD = 65;
+
+__global__ __launch_bounds__(256) void gram_inverse_kernel(const float* __restrict__ logvar, float s0,
+                                                           cmvae_causal c, float* __restrict__ out) {
+    __shared__ __align__(16) float CT[D * CT_LD];   // CT[j][i] = C[i][j]
+    __shared__ float Ms[D * MS_LD];
+    __shared__ float prow[D];
+    __shared__ float pcol[D];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = blockIdx.x;
+    // lane = input dim i
+    float s = s0;
+    if (logvar) s = expf(0.5f * logvar[(size_t)m * D + lane]) * s0;
+    if (c.linear) {
+        // C = S (I - A): C[i][j] = s_i (delta_ij - A[i][j])
+        for (int j = w; j < D; j += 4) {
+            float a = c.W[lane * D + j];
+            CT[j * CT_LD + lane] = s * ((lane == j ? 1.f : 0.f) - a);
+        }
+    } else {
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * w + jj;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int mm = 0; mm < M1; ++mm) {
+                const int u = 32 * j + mm;
+                float pre = fmaf(s, c.W[(size_t)u * D + lane], c.b1[u]);
+                acc = fmaf(elu_f(pre), c.w2[u], acc);
+            }
+            CT[j * CT_LD + lane] = (lane == j ? s : 0.f) - (acc + c.b2[j]);
+        }
+    }
+    __syncthreads();
+    // M = I + C C^T, 4x4 register tile per thread
+    {
+        const int ti = tid >> 4, tk = tid & 15;
+        float acc[4][4] = {};
+        for (int j = 0; j < D; ++j) {
+            const float4 a = *reinterpret_cast<const float4*>(&CT[j * CT_LD + 4 * ti]);
+            const float4 b = *reinterpret_cast<const float4*>(&CT[j * CT_LD + 4 * tk]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[p][q] = fmaf(av[p], bv[q], acc[p][q]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 4 * ti + p, k = 4 * tk + q;
+                Ms[i * MS_LD + k] = acc[p][q] + (i == k ? 1.f : 0.f);
+            }
+    }
+    __syncthreads();
+    // in-place Gauss-Jordan (SPD, eigenvalues >= 1: no pivoting needed)
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    for (int p = 0; p < D; ++p) {
+        if (tid < D) {
+            prow[tid] = Ms[p * MS_LD + tid];
+            pcol[tid] = Ms[tid * MS_LD + p];
+        }
+        __syncthreads();
+        const float dinv = 1.f / prow[p];
+        const float f = pcol[r];
+        if (r == p) {
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const int col = c0 + cc;
+                Ms[r * MS_LD + col] = (col == p) ? dinv : prow[col] * dinv;
+            }
+        } else {
+            const float fd = f * dinv;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const int col = c0 + cc;
+                const float old = Ms[r * MS_LD + col];
+                Ms[r * MS_LD + col] = (col == p) ? -fd : fmaf(-fd, prow[col], old);
+            }
+        }
+        __syncthreads();
+    }
+    float* o = out + (size_t)m * D * D;
+    for (int e = tid; e < D * D; e += 256) o[e] = Ms[(e >> 6) * MS_LD + (e & 63)];
+}
+
+// ------------------------------------------------------------------ the E/M pass
+constexpr int TR = 64;        // rows per tile
+constexpr int ZS_LD = 68;     // z tile leading dim: 16-B aligned rows, conflict-free b128 row reads
+
+struct PassArgs {
+    const float* z;        // [B,N,64]
+    const float* mu;       // [B,K,64]
+    const float* logw;     // [B,K]
+    const int64_t* labels; // [B,N] or null: responsibilities = one_hot(label)
+    const float* g;        // [B,N] or null: weight rows by g (backward)
+    float* part_N;         // [B,nblk,32] or null
+    float* part_S1;        // [B,nblk,K,64] or null
+    float* part_S2;        // [B,nblk,K,64] or null
+    float* lse;            // [B,N] or null
+    float* dz;             // [B,N,64] or null
+    int N, K, tiles_per_block, nblk;
+};
+
+// Load a 64-row tile of z into LDS (coalesced float4), rows >= N zero-filled.
+__device__ __forceinline__ void load_tile(const float* __restrict__ zb, int row0, int N, float* zs) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = tid + 256 * it;       // float4 index within the tile: 64 rows x 16
+        const int r = e >> 4, q = e & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < N) v = reinterpret_cast<const float4*>(zb + (size_t)(row0 + r) * D)[q];
+        *reinterpret_cast<float4*>(&zs[r * ZS_LD + 4 * q]) = v;
+    }
+}
+
+// responsibilities of a tile: on entry lls[row][k] holds the joint log-likelihoods; on exit
+// r (optionally scaled).  4 threads per row.  Returns the row's logsumexp to the caller.
+template <int KQ>
+__device__ __forceinline__ float softmax_rows(float* lls, int K) {
+    constexpr int KP = 4 * KQ;
+    constexpr int LD = KP + 1;
+    const int row = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    float v[KQ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        const int k = sub + 4 * j;
+        v[j] = (k < K) ? lls[row * LD + k] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) sum += expf(v[j] - mx);
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    const float lse = mx + logf(sum);
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        const int k = sub + 4 * j;
+        if (k < KP) lls[row * LD + k] = (k < K) ? expf(v[j] - lse) : 0.f;
+    }
+    return lse;
+}
+
+template <int KQ>
+__global__ __launch_bounds__(256) void em_pass_kernel(PassArgs a) {
+    constexpr int KP = 4 * KQ;
+    constexpr int LD = KP + 1;
+    __shared__ __align__(16) float zs[TR * ZS_LD];
+    __shared__ __align__(16) float mus[KP * D];
+    __shared__ float lls[TR * LD];
+    __shared__ float lws[KP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int N = a.N, K = a.K;
+    const float* zb = a.z + (size_t)b * N * D;
+
+    if (a.mu) {
+        for (int e = tid; e < KP * D; e += 256) mus[e] = (e < K * D) ? a.mu[(size_t)b * K * D + e] : 0.f;
+        if (tid < KP) lws[tid] = (tid < K) ? a.logw[b * K + tid] : -INFINITY;
+    }
+    const bool mstep = a.part_S1 != nullptr;
+    const bool mom2 = a.part_S2 != nullptr;
+    float s1[KQ], s2[KQ];
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) s1[j] = s2[j] = 0.f;
+    float nk = 0.f;   // thread k < KP accumulates N_k
+
+    for (int t = 0; t < a.tiles_per_block; ++t) {
+        const int row0 = (blk * a.tiles_per_block + t) * TR;
+        if (row0 >= N) break;          // uniform across the block
+        __syncthreads();               // previous tile fully consumed (also covers mus/lws stores)
+        load_tile(zb, row0, N, zs);
+        __syncthreads();
+        const int row = lane;          // E-step: lane = row, wave = component residue
+        const bool valid = row0 + row < N;
+        if (a.labels) {
+            const int64_t lab = valid ? a.labels[(size_t)b * N + row0 + row] : -1;
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const int k = w + 4 * j;
+                lls[row * LD + k] = (lab == k) ? 1.f : 0.f;
+            }
+            __syncthreads();
+        } else {
+            float zr[D];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&zs[row * ZS_LD + 4 * q]);
+                zr[4 * q] = v.x; zr[4 * q + 1] = v.y; zr[4 * q + 2] = v.z; zr[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const int k = w + 4 * j;
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float4 m = *reinterpret_cast<const float4*>(&mus[k * D + 4 * q]);
+                    float d0 = zr[4 * q] - m.x, d1 = zr[4 * q + 1] - m.y;
+                    float d2 = zr[4 * q + 2] - m.z, d3 = zr[4 * q + 3] - m.w;
+                    acc = fmaf(d0, d0, acc);
+                    acc = fmaf(d1, d1, acc);
+                    acc = fmaf(d2, d2, acc);
+                    acc = fmaf(d3, d3, acc);
+                }
+                lls[row * LD + k] = fmaf(-0.5f, acc, D * LOG_NORM) + lws[k];
+            }
+            __syncthreads();
+            const float lse = softmax_rows<KQ>(lls, K);
+            const int srow = tid >> 2;
+            if (a.lse && (tid & 3) == 0 && row0 + srow < N) a.lse[(size_t)b * N + row0 + srow] = lse;
+            {
+                // zero (or g-scale) the responsibilities; padded rows contribute nothing
+                const bool sv = row0 + srow < N;
+                const float gs = !sv ? 0.f : (a.g ? a.g[(size_t)b * N + row0 + srow] : 1.f);
+                if (gs != 1.f) {
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j) lls[srow * LD + (tid & 3) + 4 * j] *= gs;
+                }
+            }
+            __syncthreads();
+        }
+        // N_k partial
+        if (a.part_N && tid < KP) {
+            float acc = 0.f;
+            for (int r = 0; r < TR; ++r) acc += lls[r * LD + tid];
+            nk += acc;
+        }
+        if (mstep) {
+            // thread: d = lane, components k = w + 4j
+            for (int r = 0; r < TR; ++r) {
+                const float zv = zs[r * ZS_LD + lane];
+                const float zv2 = zv * zv;
+#pragma unroll
+                for (int j = 0; j < KQ; ++j) {
+                    const float rv = lls[r * LD + w + 4 * j];
+                    s1[j] = fmaf(rv, zv, s1[j]);
+                    if (mom2) s2[j] = fmaf(rv, zv2, s2[j]);
+                }
+            }
+        }
+        if (a.dz) {
+            // dz[row][d] = sum_k w_k mu_k[d] - z[d] * sum_k w_k   (w = g * r)
+            for (int rr = 0; rr < 16; ++rr) {
+                const int r = 16 * w + rr;
+                if (row0 + r >= N) break;
+                float acc = 0.f, ws = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    const float rv = lls[r * LD + k];
+                    acc = fmaf(rv, mus[k * D + lane], acc);
+                    ws += rv;
+                }
+                a.dz[((size_t)b * N + row0 + r) * D + lane] = acc - zs[r * ZS_LD + lane] * ws;
+            }
+        }
+    }
+    if (a.part_N && tid < 32) a.part_N[((size_t)b * a.nblk + blk) * 32 + tid] = (tid < KP) ? nk : 0.f;
+    if (mstep) {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const int k = w + 4 * j;
+            if (k < K) {
+                const size_t o = (((size_t)b * a.nblk + blk) * K + k) * D + lane;
+                a.part_S1[o] = s1[j];
+                if (mom2) a.part_S2[o] = s2[j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ finalize (M-step tail)
+struct FinArgs {
+    // partial sums of the unlabeled pass
+    const float* part_N; const float* part_S1; const float* part_S2;
+    int nblk;
+    // supervised sums (semi) — already reduced: [B,K], [B,K,64], [B,K,64]
+    const float* sN; const float* sS1; const float* sS2;
+    // init: gather rows of z
+    const float* z; const int64_t* init_idx; int N;
+    const float* minv;      // shared [64,64] (minv_stride == 0) or per (b,k) [B,K,64,64]
+    size_t minv_stride;
+    int K; int fix_pi; int semi; int init;
+    float tau_new;          // gamma1 (or 1 for init)
+    cmvae_causal c;
+    float* pi; float* mu; float* logvar; float* tau; float* logw;
+};
+
+__global__ __launch_bounds__(256) void em_finalize_kernel(FinArgs a) {
+    __shared__ float red[4 * D];
+    __shared__ float red2[4 * D];
+    __shared__ float nred[8 * 32];
+    __shared__ __align__(16) float ms[D];
+    __shared__ __align__(16) float xs[D];
+    __shared__ __align__(16) float es[D];
+    __shared__ float nall[32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int k = blockIdx.x, b = blockIdx.y, K = a.K;
+    float S1 = 0.f, S2 = 0.f, Nk = 0.f, pi_k = 1.f / K;
+    float uN = 0.f;
+
+    if (a.init && !a.semi) {
+        // mean0 = z[idx] (then shrunk below)
+        if (tid < D) ms[tid] = a.z[((size_t)b * a.N + a.init_idx[b * K + k]) * D + tid];
+    } else if (a.init && a.semi) {
+        if (tid < D) ms[tid] = a.sS1[((size_t)b * K + k) * D + tid] / a.sN[b * K + k];
+    } else {
+        // ---- N_k' for every component (needed for pi), fixed-order reduction
+        {
+            const int kk = tid & 31, ch = tid >> 5;   // 8 chunks of blocks
+            float acc = 0.f;
+            for (int i = ch; i < a.nblk; i += 8) acc += a.part_N[((size_t)b * a.nblk + i) * 32 + kk];
+            nred[ch * 32 + kk] = acc;
+        }
+        // ---- S1 (and S2) for this component
+        {
+            float acc = 0.f, acc2 = 0.f;
+            for (int i = w; i < a.nblk; i += 4) {
+                const size_t o = (((size_t)b * a.nblk + i) * K + k) * D + lane;
+                acc += a.part_S1[o];
+                if (a.part_S2) acc2 += a.part_S2[o];
+            }
+            red[w * D + lane] = acc;
+            red2[w * D + lane] = acc2;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float acc = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) acc += nred[ch * 32 + tid];
+            nall[tid] = acc;
+        }
+        __syncthreads();
+        uN = nall[k];
+        S1 = (red[lane] + red[D + lane]) + (red[2 * D + lane] + red[3 * D + lane]);
+        S2 = (red2[lane] + red2[D + lane]) + (red2[2 * D + lane] + red2[3 * D + lane]);
+        if (!a.semi) {
+            // N guard, then pi from the guarded N (omniglot/model.py:192-207)
+            float ntot = 0.f;
+            for (int kk = 0; kk < K; ++kk) {
+                float v = nall[kk];
+                ntot += (v == 0.f) ? 1e-22f : v;
+            }
+            Nk = (uN == 0.f) ? 1e-22f : uN;
+            if (!a.fix_pi) pi_k = Nk / ntot;
+            if (tid < D) ms[tid] = S1 / Nk;
+        } else {
+            Nk = a.sN[b * K + k] + uN;     // joint denominator
+            if (tid < D) ms[tid] = (a.sS1[((size_t)b * K + k) * D + tid] + S1) / Nk;
+        }
+    }
+    __syncthreads();
+    // ---- shrink: mean = m (row vector) @ Minv
+    {
+        const float* Mi = a.minv + (a.minv_stride ? ((size_t)b * K + k) * a.minv_stride : 0);
+        float acc = 0.f;
+#pragma unroll 4
+        for (int i = 16 * w; i < 16 * w + 16; ++i) acc = fmaf(ms[i], Mi[i * D + lane], acc);
+        red[w * D + lane] = acc;
+    }
+    __syncthreads();
+    if (tid < D) {
+        const float mean = (red[tid] + red[D + tid]) + (red[2 * D + tid] + red[3 * D + tid]);
+        xs[tid] = mean;
+        a.mu[((size_t)b * K + k) * D + tid] = mean;
+        if (a.semi) {
+            float lv = 0.f;
+            if (!a.init) {
+                const float sS1 = a.sS1[((size_t)b * K + k) * D + tid];
+                const float sS2 = a.sS2[((size_t)b * K + k) * D + tid];
+                const float sN = a.sN[b * K + k];
+                const float m2 = mean * mean;
+                const float svar = sS2 - 2.f * (mean * sS1) + sN * m2;
+                const float uvar = S2 - 2.f * (mean * S1) + uN * m2;
+                lv = logf((svar + uvar) / Nk);
+            }
+            a.logvar[((size_t)b * K + k) * D + tid] = lv;
+        }
+    }
+    __syncthreads();
+    // ---- prior term of the next E-step: log pi + glp(causal(mean), log tau)
+    causal_row_256(xs, es, a.c);
+    __syncthreads();
+    if (tid < D) {
+        const float p = prior_term_wave0(es, logf(a.tau_new));
+        if (tid == 0) {
+            a.pi[b * K + k] = pi_k;
+            a.tau[b * K + k] = a.tau_new;
+            a.logw[b * K + k] = logf(pi_k) + p;
+        }
+    }
+}
+
+// reduce the label-pass partials once: sN [B,K], sS1/sS2 [B,K,64]
+__global__ __launch_bounds__(64) void sup_reduce_kernel(const float* __restrict__ part_N,
+                                                        const float* __restrict__ part_S1,
+                                                        const float* __restrict__ part_S2, int nblk, int K,
+                                                        float* __restrict__ sN, float* __restrict__ sS1,
+                                                        float* __restrict__ sS2) {
+    const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    float a1 = 0.f, a2 = 0.f, n = 0.f;
+    for (int i = 0; i < nblk; ++i) {
+        const size_t o = (((size_t)b * nblk + i) * K + k) * D + lane;
+        a1 += part_S1[o];
+        a2 += part_S2[o];
+        n += part_N[((size_t)b * nblk + i) * 32 + k];
+    }
+    sS1[((size_t)b * K + k) * D + lane] = a1;
+    sS2[((size_t)b * K + k) * D + lane] = a2;
+    if (lane == 0) sN[b * K + k] = n;
+}
+
+// dlogw[b,k] = sum over blocks of part_N
+__global__ __launch_bounds__(64) void partn_reduce_kernel(const float* __restrict__ part_N, int nblk, int K,
+                                                          float* __restrict__ out) {
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int i = 0; i < nblk; ++i) acc += part_N[((size_t)b * nblk + i) * 32 + k];
+    out[b * K + k] = acc;
+}
+
+// ------------------------------------------------------------------ few-shot posterior + argmax
+// One block per group of `ipb` query items (rows = ipb*M <= 64) or per item (M > 64).
+template <int KQ>
+__global__ __launch_bounds__(256) void posterior_argmax_kernel(const float* __restrict__ z,
+                                                               const float* __restrict__ mu,
+                                                               const float* __restrict__ logvar,
+                                                               const float* __restrict__ logw, int te, int M,
+                                                               int K, int ipb, int64_t* __restrict__ y_pred,
+                                                               float* __restrict__ post_mean) {
+    constexpr int KP = 4 * KQ;
+    constexpr int LD = KP + 1;
+    __shared__ __align__(16) float zs[TR * ZS_LD];
+    __shared__ __align__(16) float mus[KP * D];
+    __shared__ __align__(16) float lvs[KP * D];
+    __shared__ __align__(16) float evs[KP * D];
+    __shared__ float lls[TR * LD];
+    __shared__ float lws[KP];
+    __shared__ float pm[64 * KP];   // [items(<=64)][KP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y;
+    const int item0 = blockIdx.x * ipb;
+    const int items = min(ipb, te - item0);
+    const int N = te * M;
+    const float* zb = z + (size_t)b * N * D;
+    for (int e = tid; e < KP * D; e += 256) {
+        const bool ok = e < K * D;
+        const float lv = ok ? logvar[(size_t)b * K * D + e] : 0.f;
+        mus[e] = ok ? mu[(size_t)b * K * D + e] : 0.f;
+        lvs[e] = lv;
+        evs[e] = expf(lv);
+    }
+    if (tid < KP) lws[tid] = (tid < K) ? logw[b * K + tid] : -INFINITY;
+    for (int e = tid; e < 64 * KP; e += 256) pm[e] = 0.f;
+    const int rows_total = items * M;
+    const int row_base = item0 * M;
+    for (int t0 = 0; t0 < rows_total; t0 += TR) {
+        __syncthreads();
+        // tile rows [row_base+t0, +64) limited to this block's rows
+        {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int e = tid + 256 * it;
+                const int r = e >> 4, q = e & 15;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t0 + r < rows_total) v = reinterpret_cast<const float4*>(zb + (size_t)(row_base + t0 + r) * D)[q];
+                *reinterpret_cast<float4*>(&zs[r * ZS_LD + 4 * q]) = v;
+            }
+        }
+        __syncthreads();
+        const int row = lane;
+        float zr[D];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(&zs[row * ZS_LD + 4 * q]);
+            zr[4 * q] = v.x; zr[4 * q + 1] = v.y; zr[4 * q + 2] = v.z; zr[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const int k = w + 4 * j;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int d = 0; d < D; ++d) {
+                const float df = zr[d] - mus[k * D + d];
+                acc += lvs[k * D + d] + (df * df) / evs[k * D + d];
+            }
+            lls[row * LD + k] = fmaf(-0.5f, acc, D * LOG_NORM) + lws[k];
+        }
+        __syncthreads();
+        softmax_rows<KQ>(lls, K);
+        __syncthreads();
+        // accumulate per item: thread (item-local row range) -> pm[item][k]
+        // one thread per (item, k) pair sums its rows of this tile in ascending order
+        for (int e = tid; e < 64 * KP; e += 256) {
+            const int il = e / KP, k = e % KP;      // item slot within the block
+            if (il < items && k < K) {
+                const int r_lo = max(il * M - t0, 0), r_hi = min((il + 1) * M - t0, TR);
+                float acc = pm[e];
+                for (int r = r_lo; r < r_hi; ++r) acc += lls[r * LD + k];
+                pm[e] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < items) {
+        int best = 0;
+        float bv = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const float v = pm[tid * KP + k] / (float)M;
+            if (post_mean) post_mean[((size_t)b * te + item0 + tid) * K + k] = v;
+            if (v > bv) { bv = v; best = k; }
+        }
+        y_pred[(size_t)b * te + item0 + tid] = best;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static int pick_tiles_per_block(int B, int N) {
+    const int tiles_ep = (N + TR - 1) / TR;
+    const long total = (long)tiles_ep * B;
+    int tpb = (int)(total / 384);
+    if (tpb < 1) tpb = 1;
+    if (tpb > tiles_ep) tpb = tiles_ep;
+    return tpb;
+}
+static int nblk_for(int N, int tpb) {
+    const int tiles_ep = (N + TR - 1) / TR;
+    return (tiles_ep + tpb - 1) / tpb;
+}
+
+template <typename F>
+static int dispatch_kq(int K, F&& f) {
+    const int kq = (K + 3) / 4;
+    switch (kq) {
+        case 1: return f(std::integral_constant<int, 1>{});
+        case 2: return f(std::integral_constant<int, 2>{});
+        case 3: return f(std::integral_constant<int, 3>{});
+        case 4: return f(std::integral_constant<int, 4>{});
+        case 5: return f(std::integral_constant<int, 5>{});
+        case 6: return f(std::integral_constant<int, 6>{});
+        case 7: return f(std::integral_constant<int, 7>{});
+        case 8: return f(std::integral_constant<int, 8>{});
+    }
+    return set_error("component count K=%d outside [1,%d]", K, CMVAE_KMAX);
+}
+
+static int launch_pass(const PassArgs& a, int B, hipStream_t st) {
+    return dispatch_kq(a.K, [&](auto kq) {
+        constexpr int KQ = decltype(kq)::value;
+        hipLaunchKernelGGL(em_pass_kernel<KQ>, dim3(a.nblk, B), dim3(256), 0, st, a);
+        return check_launch("em_pass_kernel");
+    });
+}
+
+static int check_causal(const cmvae_causal* c) {
+    CMVAE_REQUIRE(c != nullptr, "causal descriptor is NULL");
+    CMVAE_REQUIRE(c->W != nullptr, "causal.W is NULL");
+    if (!c->linear) CMVAE_REQUIRE(c->b1 && c->w2 && c->b2, "nonlinear causal layer needs b1, w2, b2");
+    return 0;
+}
+
+struct EmWorkspace {
+    float *minv0, *minv, *part_N, *part_S1, *part_S2, *sN, *sS1, *sS2, *spart_N, *spart_S1, *spart_S2;
+    size_t bytes;
+};
+
+static EmWorkspace carve(void* base, int B, int Nu, int Ns, int K, bool semi) {
+    EmWorkspace w{};
+    size_t off = 0;
+    auto take = [&](size_t nfloat) {
+        float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+        off += align_up(nfloat * sizeof(float));
+        return p;
+    };
+    const int tpb = pick_tiles_per_block(B, Nu), nblk = nblk_for(Nu, tpb);
+    w.minv0 = take(D * D);
+    w.minv = take(semi ? (size_t)B * K * D * D : D * D);
+    w.part_N = take((size_t)B * nblk * 32);
+    w.part_S1 = take((size_t)B * nblk * K * D);
+    if (semi) {
+        w.part_S2 = take((size_t)B * nblk * K * D);
+        const int stpb = pick_tiles_per_block(B, Ns), snblk = nblk_for(Ns, stpb);
+        w.spart_N = take((size_t)B * snblk * 32);
+        w.spart_S1 = take((size_t)B * snblk * K * D);
+        w.spart_S2 = take((size_t)B * snblk * K * D);
+        w.sN = take((size_t)B * K);
+        w.sS1 = take((size_t)B * K * D);
+        w.sS2 = take((size_t)B * K * D);
+    }
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace cmvae
+
+using namespace cmvae;
+
+extern "C" int cmvae_causal_rows(const float* x, int rows, const cmvae_causal* c, const float* pi, const float* tau,
+                                 float* eps, float* logw, void* stream) {
+    if (int e = check_causal(c)) return e;
+    CMVAE_REQUIRE(x && rows >= 0, "cmvae_causal_rows: bad arguments");
+    CMVAE_REQUIRE(!logw || (pi && tau), "cmvae_causal_rows: logw needs pi and tau");
+    if (rows == 0) return 0;
+    const int grid = rows < 4096 ? rows : 4096;
+    hipLaunchKernelGGL(causal_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, rows, *c, pi, tau, eps,
+                       logw);
+    return check_launch("causal_rows_kernel");
+}
+
+extern "C" int cmvae_gram_inverse(const float* logvar, float s0, int nmat, const cmvae_causal* c, float* out,
+                                  void* stream) {
+    if (int e = check_causal(c)) return e;
+    CMVAE_REQUIRE(out && nmat >= 0, "cmvae_gram_inverse: bad arguments");
+    if (nmat == 0) return 0;
+    hipLaunchKernelGGL(gram_inverse_kernel, dim3(nmat), dim3(256), 0, (hipStream_t)stream, logvar, s0, *c, out);
+    return check_launch("gram_inverse_kernel");
+}
+
+extern "C" size_t cmvae_unsup_prior_workspace_bytes(int B, int N, int K) {
+    return carve(nullptr, B, N, 0, K, false).bytes;
+}
+
+extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int64_t* init_idx, const cmvae_causal* c,
+                                 int iters, int fix_pi, float gamma1, void* workspace, size_t workspace_bytes,
+                                 float* pi, float* mu, float* tau, float* logw, void* stream) {
+    if (int e = check_causal(c)) return e;
+    CMVAE_REQUIRE(z && init_idx && pi && mu && tau && logw, "cmvae_unsup_prior: NULL tensor");
+    CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX && iters >= 0, "cmvae_unsup_prior: bad shape B=%d N=%d K=%d",
+                  B, N, K);
+    CMVAE_REQUIRE(K <= N, "cmvae_unsup_prior: K=%d > N=%d", K, N);
+    EmWorkspace w = carve(workspace, B, N, 0, K, false);
+    CMVAE_REQUIRE(workspace && workspace_bytes >= w.bytes, "cmvae_unsup_prior: workspace %zu < %zu", workspace_bytes,
+                  w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int tpb = pick_tiles_per_block(B, N), nblk = nblk_for(N, tpb);
+    // initial inverse (tau0 = 1) and the loop inverse (tau = gamma1); both data independent
+    hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(256), 0, st, nullptr, 1.0f, *c, w.minv0);
+    if (int e = check_launch("gram_inverse_kernel")) return e;
+    const float* minv_loop = w.minv0;
+    if (gamma1 != 1.0f) {
+        hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(256), 0, st, nullptr, gamma1, *c, w.minv);
+        if (int e = check_launch("gram_inverse_kernel")) return e;
+        minv_loop = w.minv;
+    }
+    FinArgs f{};
+    f.z = z; f.init_idx = init_idx; f.N = N; f.K = K; f.fix_pi = fix_pi; f.semi = 0; f.init = 1;
+    f.minv = w.minv0; f.minv_stride = 0; f.tau_new = 1.0f; f.c = *c;
+    f.pi = pi; f.mu = mu; f.logvar = nullptr; f.tau = tau; f.logw = logw;
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(256), 0, st, f);
+    if (int e = check_launch("em_finalize_kernel(init)")) return e;
+    PassArgs p{};
+    p.z = z; p.mu = mu; p.logw = logw; p.part_N = w.part_N; p.part_S1 = w.part_S1;
+    p.N = N; p.K = K; p.tiles_per_block = tpb; p.nblk = nblk;
+    f.init = 0; f.part_N = w.part_N; f.part_S1 = w.part_S1; f.part_S2 = nullptr; f.nblk = nblk;
+    f.minv = minv_loop; f.tau_new = gamma1;
+    for (int it = 0; it < iters; ++it) {
+        if (int e = launch_pass(p, B, st)) return e;
+        hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(256), 0, st, f);
+        if (int e = check_launch("em_finalize_kernel")) return e;
+    }
+    return 0;
+}
+
+extern "C" size_t cmvae_semi_prior_workspace_bytes(int B, int Nu, int Ns, int K) {
+    return carve(nullptr, B, Nu, Ns, K, true).bytes;
+}
+
+extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t* y, int B, int Nu, int Ns, int K,
+                                const cmvae_causal* c, int iters, float gamma1, void* workspace,
+                                size_t workspace_bytes, float* pi, float* mu, float* logvar, float* tau, float* logw,
+                                void* stream) {
+    if (int e = check_causal(c)) return e;
+    CMVAE_REQUIRE(uz && sz && y && pi && mu && logvar && tau && logw, "cmvae_semi_prior: NULL tensor");
+    CMVAE_REQUIRE(B > 0 && Nu > 0 && Ns > 0 && K >= 1 && K <= CMVAE_KMAX && iters >= 0,
+                  "cmvae_semi_prior: bad shape B=%d Nu=%d Ns=%d K=%d", B, Nu, Ns, K);
+    EmWorkspace w = carve(workspace, B, Nu, Ns, K, true);
+    CMVAE_REQUIRE(workspace && workspace_bytes >= w.bytes, "cmvae_semi_prior: workspace %zu < %zu", workspace_bytes,
+                  w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int tpb = pick_tiles_per_block(B, Nu), nblk = nblk_for(Nu, tpb);
+    const int stpb = pick_tiles_per_block(B, Ns), snblk = nblk_for(Ns, stpb);
+    // supervised sums (constant over the loop): y^T sz, y^T sz^2, sum y
+    PassArgs s{};
+    s.z = sz; s.labels = y; s.part_N = w.spart_N; s.part_S1 = w.spart_S1; s.part_S2 = w.spart_S2;
+    s.N = Ns; s.K = K; s.tiles_per_block = stpb; s.nblk = snblk;
+    if (int e = launch_pass(s, B, st)) return e;
+    hipLaunchKernelGGL(sup_reduce_kernel, dim3(K, B), dim3(64), 0, st, w.spart_N, w.spart_S1, w.spart_S2, snblk, K,
+                       w.sN, w.sS1, w.sS2);
+    if (int e = check_launch("sup_reduce_kernel")) return e;
+    hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(256), 0, st, nullptr, 1.0f, *c, w.minv0);
+    if (int e = check_launch("gram_inverse_kernel")) return e;
+    FinArgs f{};
+    f.K = K; f.fix_pi = 1; f.semi = 1; f.init = 1; f.sN = w.sN; f.sS1 = w.sS1; f.sS2 = w.sS2;
+    f.minv = w.minv0; f.minv_stride = 0; f.tau_new = 1.0f; f.c = *c;
+    f.pi = pi; f.mu = mu; f.logvar = logvar; f.tau = tau; f.logw = logw;
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(256), 0, st, f);
+    if (int e = check_launch("em_finalize_kernel(semi init)")) return e;
+    PassArgs p{};
+    p.z = uz; p.mu = mu; p.logw = logw; p.part_N = w.part_N; p.part_S1 = w.part_S1; p.part_S2 = w.part_S2;
+    p.N = Nu; p.K = K; p.tiles_per_block = tpb; p.nblk = nblk;
+    f.init = 0; f.part_N = w.part_N; f.part_S1 = w.part_S1; f.part_S2 = w.part_S2; f.nblk = nblk;
+    f.minv = w.minv; f.minv_stride = (size_t)D * D; f.tau_new = gamma1;
+    for (int it = 0; it < iters; ++it) {
+        // inverse from the incoming logvar and tau = gamma1 (omniglot/model.py:259-265)
+        hipLaunchKernelGGL(gram_inverse_kernel, dim3(B * K), dim3(256), 0, st, logvar, gamma1, *c, w.minv);
+        if (int e = check_launch("gram_inverse_kernel")) return e;
+        if (int e = launch_pass(p, B, st)) return e;
+        hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(256), 0, st, f);
+        if (int e = check_launch("em_finalize_kernel")) return e;
+    }
+    return 0;
+}
+
+extern "C" int cmvae_posterior_argmax(const float* z, const float* mu, const float* logvar, const float* logw, int B,
+                                      int te, int M, int K, int64_t* y_pred, float* post_mean, void* stream) {
+    CMVAE_REQUIRE(z && mu && logvar && logw && y_pred, "cmvae_posterior_argmax: NULL tensor");
+    CMVAE_REQUIRE(B > 0 && te > 0 && M > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_posterior_argmax: bad shape");
+    const int ipb = M >= TR ? 1 : TR / M;
+    const int grid = (te + ipb - 1) / ipb;
+    return dispatch_kq(K, [&](auto kq) {
+        constexpr int KQ = decltype(kq)::value;
+        hipLaunchKernelGGL(posterior_argmax_kernel<KQ>, dim3(grid, B), dim3(256), 0, (hipStream_t)stream, z, mu, logvar,
+                           logw, te, M, K, ipb, y_pred, post_mean);
+        return check_launch("posterior_argmax_kernel");
+    });
+}
+
+extern "C" size_t cmvae_mixture_workspace_bytes(int B, int N, int K) {
+    (void)K;
+    const int tpb = pick_tiles_per_block(B, N), nblk = nblk_for(N, tpb);
+    return align_up((size_t)B * nblk * 32 * sizeof(float));
+}
+
+extern "C" int cmvae_mixture_loglik_fwd(const float* z, const float* mu, const float* logw, int B, int N, int K,
+                                        float* lse, void* stream) {
+    CMVAE_REQUIRE(z && mu && logw && lse, "cmvae_mixture_loglik_fwd: NULL tensor");
+    CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_mixture_loglik_fwd: bad shape");
+    PassArgs p{};
+    p.z = z; p.mu = mu; p.logw = logw; p.lse = lse; p.N = N; p.K = K;
+    p.tiles_per_block = pick_tiles_per_block(B, N); p.nblk = nblk_for(N, p.tiles_per_block);
+    return launch_pass(p, B, (hipStream_t)stream);
+}
+
+extern "C" int cmvae_mixture_loglik_bwd(const float* z, const float* mu, const float* logw, const float* g, int B,
+                                        int N, int K, void* workspace, size_t workspace_bytes, float* dz, float* dlogw,
+                                        void* stream) {
+    CMVAE_REQUIRE(z && mu && logw && g && dz && dlogw, "cmvae_mixture_loglik_bwd: NULL tensor");
+    CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_mixture_loglik_bwd: bad shape");
+    CMVAE_REQUIRE(workspace && workspace_bytes >= cmvae_mixture_workspace_bytes(B, N, K),
+                  "cmvae_mixture_loglik_bwd: workspace too small");
+    PassArgs p{};
+    p.z = z; p.mu = mu; p.logw = logw; p.g = g; p.dz = dz; p.part_N = (float*)workspace; p.N = N; p.K = K;
+    p.tiles_per_block = pick_tiles_per_block(B, N); p.nblk = nblk_for(N, p.tiles_per_block);
+    if (int e = launch_pass(p, B, (hipStream_t)stream)) return e;
+    hipLaunchKernelGGL(partn_reduce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, p.nblk,
+                       K, dlogw);
+    return check_launch("partn_reduce_kernel");
+}

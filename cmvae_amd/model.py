@@ -1,0 +1,229 @@
+"""GMVAE — the episodic train (`forward`) and few-shot eval (`prediction`) hot path of CMVAE on
+MI355X.  Same constructor arguments, return values and ``state_dict`` keys as the reference
+(omniglot/model.py:14-87, 431-585; mimgnet/model.py:11-69, 364-511; celeba/model.py).
+
+Where the arithmetic runs:
+  * EM loops, causal prior term, (I+CC^T)^-1, mixture log-likelihood (fwd+bwd),
+    reparametrisation + log q (fwd+bwd), acyclicity expm trace (fwd+bwd), few-shot posterior
+    + argmax: hand-written HIP kernels behind the C-ABI (cmvae_amd/ops.py).
+  * Dense contractions (conv / conv-transpose / linear / attention) and BatchNorm currently go
+    through PyTorch-ROCm ATen ops on the GPU (MIOpen / hipBLASLt) — scaffolding that the fused
+    fp32-MFMA kernels replace (DESIGN.md "status").
+There is no CPU path: tensors must live on the GPU and the HIP library must be loadable.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .module import OmniglotEncoder, OmniglotDecoder, SAB, CausalEncoder
+
+_LOG_NORM = -0.5 * np.log(2 * np.pi)
+
+
+class _GMVAEBase(nn.Module):
+    def _init_common(self, unsupervised_em_iters, semisupervised_em_iters, fix_pi, component_size, latent_size,
+                     train_mc_sample_size, test_mc_sample_size, linear, laplace, gamma):
+        if latent_size != ops.D:
+            raise ValueError('the MI355X kernels are built for latent_size == 64 (got %d)' % latent_size)
+        if laplace:
+            raise NotImplementedError('laplace=True is never used by the reference trainers')
+        self.gamma1 = 1 / math.sqrt(gamma)
+        self.laplace = laplace
+        self.linear = linear
+        self.unsupervised_em_iters = unsupervised_em_iters
+        self.semisupervised_em_iters = semisupervised_em_iters
+        self.fix_pi = fix_pi
+        self.component_size = component_size
+        self.latent_size = latent_size
+        self.train_mc_sample_size = train_mc_sample_size
+        self.test_mc_sample_size = test_mc_sample_size
+
+    def _register_constants(self, with_log2):
+        self.register_buffer('log_norm_constant', torch.tensor(_LOG_NORM))       # float64 0-dim, as the reference
+        if with_log2:
+            self.register_buffer('log_2', torch.tensor(np.log(2)))
+        self.register_buffer('uniform_pi', torch.ones(self.component_size) / self.component_size)
+
+    # ------------------------------------------------------------------ small pieces
+    def _causal_desc(self):
+        c = self.causal
+        if c.linear:
+            return ops.Causal(True, c.A)
+        return ops.Causal(False, c.fc1.weight, c.fc1.bias, c.fc2[0].weight, c.fc2[0].bias)
+
+    def gaussian_log_prob(self, x, mean, logvar=None):
+        if logvar is None:
+            logvar = torch.zeros_like(mean)
+        return (-0.5 * (logvar + (x - mean).pow(2) / logvar.exp()) + self.log_norm_constant).sum(dim=-1)
+
+    def h_a(self, A):
+        return ops.expm_trace(A)
+
+    def _draw_eps(self, mean, S):
+        # same generator call and shape as the reference's torch.randn_like on the repeated mean
+        return torch.randn(mean.shape[0], mean.shape[1], S, mean.shape[2], device=mean.device, dtype=mean.dtype)
+
+    def _draw_init_idx(self, batch_size, sample_size, device):
+        # host numpy stream, one draw per episode in episode order (omniglot/model.py:351-356)
+        idx = np.stack([np.random.choice(sample_size, self.component_size, replace=False)
+                        for _ in range(batch_size)], 0).astype(np.int64)
+        return torch.from_numpy(idx).to(device)
+
+    def get_unsupervised_prior(self, z, init_idx=None):
+        """(pi_k, mu_k, trace_k) after `unsupervised_em_iters` EM iterations; also returns logw."""
+        if init_idx is None:
+            init_idx = self._draw_init_idx(z.shape[0], z.shape[1], z.device)
+        elif not isinstance(init_idx, torch.Tensor):
+            init_idx = torch.as_tensor(np.asarray(init_idx), dtype=torch.int64).to(z.device)
+        with torch.no_grad():
+            return ops.unsup_prior(z.detach().contiguous(), init_idx.contiguous(), self._causal_desc(),
+                                   self.unsupervised_em_iters, self.fix_pi, self.gamma1)
+
+    def get_semisupervised_prior(self, unsupervised_z, supervised_z, y):
+        """y: int64 labels [B,Ns] (or the reference's one-hot float [B,Ns,K])."""
+        if y.dim() == 3:
+            y = y.argmax(-1)
+        with torch.no_grad():
+            return ops.semi_prior(unsupervised_z.contiguous(), supervised_z.contiguous(), y.contiguous(),
+                                  self.component_size, self._causal_desc(), self.semisupervised_em_iters,
+                                  self.gamma1)
+
+    # ------------------------------------------------------------------ shared tails
+    def _kl_and_h(self, q_z, q_z4_logq, q_eps, A, h_lambda, h_c, a_lambda, init_idx, extras):
+        B = q_z.shape[0]
+        pi_k, mu_k, trace_k, _ = self.get_unsupervised_prior(q_z, init_idx)
+        # prior term with gradient to the causal parameters (mu_k, pi_k, trace_k are constants)
+        q_eps_mu_k = self.causal(mu_k)
+        logw = torch.log(pi_k) + self.gaussian_log_prob(
+            q_eps_mu_k, torch.log(trace_k)[:, :, None].expand(-1, -1, self.latent_size))
+        log_p_z = ops.mixture_loglik(q_z, mu_k, logw)                      # [B, N]
+        log_q_z = q_z4_logq                                                # [B, S, M]
+        log_p_eps = (-0.5 * q_eps.pow(2) + self.log_norm_constant).sum(-1)  # glp(q_eps, 0)
+        kl_loss = log_q_z.mean() - log_p_z.mean() - log_p_eps.mean()
+        h = self.h_a(A)
+        h_augment = h_lambda * h + 0.5 * h_c * h * h + a_lambda * A.abs().sum()
+        if extras is not None:
+            extras.update(pi_k=pi_k, mu_k=mu_k, trace_k=trace_k, log_p_z=log_p_z.view(B, -1),
+                          log_q_z=log_q_z, log_p_eps=log_p_eps, q_z=q_z, q_eps=q_eps, A=A)
+        return kl_loss, h_augment, h
+
+    def _predict_from_posterior(self, q_mean, q_logvar, y_tr, tr, te, eps, extras):
+        B = q_mean.shape[0]
+        D, Mt = self.latent_size, self.test_mc_sample_size
+        if eps is None:
+            eps = self._draw_eps(q_mean, self.train_mc_sample_size)
+        q_z, _ = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
+        # the reference samples with train_mc but reshapes with test_mc (omniglot/model.py:536 vs 542-547)
+        uz = q_z[:, tr:tr + te].reshape(B, te * Mt, D).contiguous()
+        sz = q_z[:, :tr].reshape(B, tr * Mt, D).contiguous()
+        y = y_tr.reshape(B * tr)[:, None].repeat(1, Mt).view(B, tr * Mt)
+        pi_k, mu_k, lv_k, trace, logw = self.get_semisupervised_prior(uz, sz, y)
+        y_pred, post = ops.posterior_argmax(uz, mu_k, lv_k, logw, te, Mt, want_post=extras is not None)
+        if extras is not None:
+            extras.update(pi_k=pi_k, mu_k=mu_k, logvar_k=lv_k, post_mean=post, q_z=q_z)
+        return y_pred
+
+
+class OmniglotGMVAE(_GMVAEBase):
+    """Conv-VAE variant (omniglot/model.py).  `linear` defaults to False (NOTEARS-MLP causal layer)."""
+
+    def __init__(self, input_shape=[1, 28, 28], unsupervised_em_iters=5, semisupervised_em_iters=5, fix_pi=False,
+                 hidden_size=64, component_size=20, latent_size=64, train_mc_sample_size=10,
+                 test_mc_sample_size=10, linear=False, eval_iter=15, laplace=False, gamma=1):
+        super().__init__()
+        if hidden_size != latent_size:
+            raise ValueError('hidden_size must equal latent_size (the reference splits 2*hidden into 2*latent)')
+        self._init_common(unsupervised_em_iters, semisupervised_em_iters, fix_pi, component_size, latent_size,
+                          train_mc_sample_size, test_mc_sample_size, linear, laplace, gamma)
+        self.eval_iter = eval_iter
+        self.input_shape = list(input_shape)
+        self.hidden_size = hidden_size
+        self.last_hidden_size = 2 * 2 * hidden_size
+        # construction order fixes the RNG consumption order of the seeded init
+        self.encoder = OmniglotEncoder(hidden_size=hidden_size)
+        L = self.last_hidden_size
+        self.q_z_given_H = nn.Sequential(SAB(L, L, 4, ln=False), SAB(L, L, 4, ln=False),
+                                         nn.Linear(L, 2 * hidden_size))
+        self.causal = CausalEncoder(hidden_size, linear=linear)
+        self.proj = nn.Sequential(nn.Linear(2 * latent_size, L), nn.ELU(inplace=True),
+                                  nn.Linear(L, L), nn.ELU(inplace=True),
+                                  nn.Linear(L, L), nn.ELU(inplace=True))
+        self.decoder = OmniglotDecoder(hidden_size=hidden_size)
+        self._register_constants(with_log2=True)
+
+    def _encode(self, X):
+        B, S = X.shape[:2]
+        H = self.encoder(X.reshape(-1, *self.input_shape)).view(B, S, self.last_hidden_size)
+        return self.q_z_given_H(H).split(self.latent_size, dim=-1)
+
+    def forward(self, X, h_lambda, h_c, a_lambda, eps=None, init_idx=None, extras=None):
+        B, S = X.shape[:2]
+        M, D = self.train_mc_sample_size, self.latent_size
+        q_mean, q_logvar = self._encode(X)
+        if eps is None:
+            eps = self._draw_eps(q_mean, M)
+        q_z4, log_q_z = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
+        q_z = q_z4.view(B, S * M, D)
+        q_eps = self.causal(q_z - q_z.mean(1, keepdim=True))
+        A = self.causal.get_w()
+        H_rec = self.proj(torch.cat([q_z, q_eps], -1).view(-1, 2 * D))
+        X_rec = self.decoder(H_rec).view(B, S, M, *self.input_shape)
+        target = X[:, :, None].expand(-1, -1, M, -1, -1, -1)
+        rec_loss = F.binary_cross_entropy(X_rec, target, reduction='sum') / (B * S * M)
+        kl_loss, h_augment, h = self._kl_and_h(q_z, log_q_z, q_eps, A, h_lambda, h_c, a_lambda, init_idx, extras)
+        if extras is not None:
+            extras.update(q_z_mean=q_mean, q_z_logvar=q_logvar)
+        return X_rec, rec_loss, kl_loss, h_augment, h
+
+    def prediction(self, X_tr, y_tr, X_te, eps=None, extras=None):
+        tr, te = X_tr.shape[1], X_te.shape[1]
+        with torch.no_grad():
+            q_mean, q_logvar = self._encode(torch.cat([X_tr, X_te], dim=1))
+            return self._predict_from_posterior(q_mean, q_logvar, y_tr, tr, te, eps, extras)
+
+
+class FeatureGMVAE(_GMVAEBase):
+    """MLP-VAE variant over pre-extracted SimCLR features (mimgnet/model.py; celeba/model.py with
+    linear=False)."""
+
+    def __init__(self, input_shape=512, unsupervised_em_iters=5, semisupervised_em_iters=5, fix_pi=False,
+                 component_size=20, latent_size=64, train_mc_sample_size=10, test_mc_sample_size=10, linear=True,
+                 laplace=False, gamma=1):
+        super().__init__()
+        self._init_common(unsupervised_em_iters, semisupervised_em_iters, fix_pi, component_size, latent_size,
+                          train_mc_sample_size, test_mc_sample_size, linear, laplace, gamma)
+        self.input_shape = Fd = int(input_shape)
+        self.q_z_given_H = nn.Sequential(SAB(Fd, Fd, 4, ln=False), SAB(Fd, Fd, 4, ln=False),
+                                         nn.Linear(Fd, 2 * latent_size))
+        self.causal = CausalEncoder(latent_size, linear=linear)
+        self.proj = nn.Sequential(nn.Linear(2 * latent_size, 2 * Fd), nn.ReLU(inplace=True),
+                                  nn.Linear(2 * Fd, 2 * Fd), nn.ReLU(inplace=True),
+                                  nn.Linear(2 * Fd, Fd), nn.ReLU(inplace=True))
+        self._register_constants(with_log2=False)
+
+    def forward(self, H, h_lambda, h_c, a_lambda, eps=None, init_idx=None, extras=None):
+        B, S = H.shape[:2]
+        M, D = self.train_mc_sample_size, self.latent_size
+        q_mean, q_logvar = self.q_z_given_H(H).split(D, dim=-1)
+        if eps is None:
+            eps = self._draw_eps(q_mean, M)
+        q_z4, log_q_z = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
+        q_z = q_z4.view(B, S * M, D)
+        q_eps = self.causal(q_z)
+        A = self.causal.get_w()
+        H_rec = self.proj(torch.cat([q_z, q_eps], -1).view(-1, 2 * D)).view(B, S, M, self.input_shape)
+        rec_loss = (H_rec - H[:, :, None]).pow(2).sum() / (B * S * M)
+        kl_loss, h_augment, h = self._kl_and_h(q_z, log_q_z, q_eps, A, h_lambda, h_c, a_lambda, init_idx, extras)
+        if extras is not None:
+            extras.update(q_z_mean=q_mean, q_z_logvar=q_logvar)
+        return H_rec, rec_loss, kl_loss, h_augment, h
+
+    def prediction(self, H_tr, y_tr, H_te, eps=None, extras=None):
+        tr, te = H_tr.shape[1], H_te.shape[1]
+        with torch.no_grad():
+            q_mean, q_logvar = self.q_z_given_H(torch.cat([H_tr, H_te], dim=1)).split(self.latent_size, dim=-1)
+            return self._predict_from_posterior(q_mean, q_logvar, y_tr, tr, te, eps, extras)

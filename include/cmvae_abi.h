@@ -1,0 +1,128 @@
+/*
+ * cmvae_abi.h — C-ABI of libcmvae_hip.so, the MI355X (gfx950) hot path of CMVAE's episodic
+ * train / eval step.
+ *
+ * The reference (GuodongQi/CMVAE) has no FFI/plugin layer: its boundary is the Python
+ * surface of GMVAE.  These entry points are what the Python host in
+ * cmvae_amd/ binds through ctypes (cmvae_amd/_lib.py); each one cites the reference
+ * function (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HIP, gfx950) unless a name ends in _host;
+ *     tensors are dense row-major fp32, labels / indices int64.
+ *   - the caller owns every buffer, including `workspace` (size from the matching
+ *     *_workspace_bytes query); no entry point allocates, frees or synchronises.
+ *   - kernels are enqueued on `stream` (a hipStream_t; NULL = default stream) and the
+ *     call returns immediately.
+ *   - return 0 on success, negative on error; cmvae_last_error() gives a thread-local
+ *     message.  Shape limits: latent size D == 64, locally-connected width 32,
+ *     1 <= K <= 32.
+ *   - entry points keep no global state; they are re-entrant across host threads.
+ */
+#ifndef CMVAE_ABI_H
+#define CMVAE_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMVAE_D 64        /* latent size the kernels are built for            */
+#define CMVAE_M1 32       /* hidden units per latent dim in the NOTEARS-MLP   */
+#define CMVAE_KMAX 32     /* max mixture components                           */
+
+/* The causal layer (omniglot/module.py:136-196, mimgnet/module.py:47-110).
+ * linear != 0 : mask(x) = x @ A,            W = A            [64,64]
+ * linear == 0 : mask(x) = LC(ELU(fc1 x)),   W = fc1.weight   [2048,64], b1 = fc1.bias [2048],
+ *               w2 = fc2.0.weight [64,32(,1)], b2 = fc2.0.bias [64(,1)]               */
+typedef struct cmvae_causal {
+    int32_t linear;
+    const float* W;
+    const float* b1;
+    const float* w2;
+    const float* b2;
+} cmvae_causal;
+
+const char* cmvae_last_error(void);
+int cmvae_abi_version(void);
+
+/* ---- causal layer on a small number of rows -------------------------------------------
+ * eps[r,:] = x[r,:] - mask(x[r,:])                  CausalEncoder.forward, omniglot/module.py:165-188
+ * Optionally also logw[r] = log(pi[r]) + glp(eps[r,:], log(tau[r]))  — the per-component prior
+ * term of every E-step (omniglot/model.py:177-184).  eps / logw / pi / tau may be NULL.       */
+int cmvae_causal_rows(const float* x, int rows, const cmvae_causal* c,
+                      const float* pi, const float* tau,
+                      float* eps, float* logw, void* stream);
+
+/* ---- (I + C C^T)^-1, C row i = causal(s_i e_i) -----------------------------------------
+ * replaces `std_causal = causal(diag(...)); inverse(I + std_causal @ std_causal^T)`
+ * (omniglot/model.py:199-203, 259-265, 342-348).
+ * scale: [nmat,64] per-row scales s (semi-EM: exp(0.5*logvar)*tau), or NULL with scalar `s0`
+ * (unsupervised: tau).  logvar != NULL means s = exp(0.5*logvar[m,i]) * s0.
+ * out: [nmat,64,64].                                                                         */
+int cmvae_gram_inverse(const float* logvar, float s0, int nmat, const cmvae_causal* c,
+                       float* out, void* stream);
+
+/* ---- unsupervised EM prior: GMVAE.get_unsupervised_prior (omniglot/model.py:332-368)
+ * with get_unsupervised_params (168-222) as the loop body.
+ * z [B,N,64]; init_idx [B,K] int64 rows of z that seed the means (the reference draws them
+ * with np.random.choice on the host, model.py:351-356 — the caller still does).
+ * Outputs pi [B,K], mu [B,K,64], tau [B,K], logw [B,K] (= log pi + glp(causal(mu), log tau),
+ * the term the next consumer adds to every log-likelihood).                                  */
+size_t cmvae_unsup_prior_workspace_bytes(int B, int N, int K);
+int cmvae_unsup_prior(const float* z, int B, int N, int K, const int64_t* init_idx,
+                      const cmvae_causal* c, int iters, int fix_pi, float gamma1,
+                      void* workspace, size_t workspace_bytes,
+                      float* pi, float* mu, float* tau, float* logw, void* stream);
+
+/* ---- semi-supervised EM prior: GMVAE.get_semisupervised_prior (omniglot/model.py:370-412)
+ * with get_semisupervised_params (224-330) as the loop body.
+ * uz [B,Nu,64] unlabeled latents, sz [B,Ns,64] labeled latents, y [B,Ns] int64 labels in
+ * [0,K) (the reference passes one_hot(y).float(); model.py:550-554).
+ * Outputs pi [B,K] (uniform: never updated, model.py:330), mu, logvar [B,K,64], tau, logw.  */
+size_t cmvae_semi_prior_workspace_bytes(int B, int Nu, int Ns, int K);
+int cmvae_semi_prior(const float* uz, const float* sz, const int64_t* y,
+                     int B, int Nu, int Ns, int K,
+                     const cmvae_causal* c, int iters, float gamma1,
+                     void* workspace, size_t workspace_bytes,
+                     float* pi, float* mu, float* logvar, float* tau, float* logw, void* stream);
+
+/* ---- final few-shot posterior: GMVAE.prediction tail (omniglot/model.py:564-583)
+ * ll = glp(z, mu_k, logvar_k) + logw_k ; post = exp(ll - logsumexp) ; mean over the M
+ * samples of each query item ; argmax over K.  z [B, te*M, 64]; y_pred [B,te] int64;
+ * post_mean [B,te,K] optional (NULL to skip).                                               */
+int cmvae_posterior_argmax(const float* z, const float* mu, const float* logvar, const float* logw,
+                           int B, int te, int M, int K,
+                           int64_t* y_pred, float* post_mean, void* stream);
+
+/* ---- mixture log-likelihood with gradient (omniglot/model.py:475-494)
+ * fwd: lse[b,n] = logsumexp_k( glp(z[b,n], mu[b,k]) + logw[b,k] )
+ * bwd: dz[b,n,:] = g[b,n] * sum_k r_k (mu_k - z) ; dlogw[b,k] = sum_n g[b,n] r[b,n,k]
+ * workspace: cmvae_mixture_workspace_bytes(B,N,K) (per-block partials of dlogw).           */
+size_t cmvae_mixture_workspace_bytes(int B, int N, int K);
+int cmvae_mixture_loglik_fwd(const float* z, const float* mu, const float* logw,
+                             int B, int N, int K, float* lse, void* stream);
+int cmvae_mixture_loglik_bwd(const float* z, const float* mu, const float* logw, const float* g,
+                             int B, int N, int K, void* workspace, size_t workspace_bytes,
+                             float* dz, float* dlogw, void* stream);
+
+/* ---- reparametrisation + log q(z|x) (omniglot/model.py:111-122, 496-501)
+ * z[r,m,:] = eps[r,m,:]*exp(0.5*logvar[r,:]) + mean[r,:] ; logq[r,m] = glp(z, mean, logvar)
+ * rows = B*S, mean/logvar [rows,64], eps/z [rows,M,64], logq [rows,M] (may be NULL).
+ * bwd: dmean[r,:] = sum_m gz ; dlogvar[r,:] = sum_m gz*0.5*eps*std - 0.5*sum_m glogq
+ *      (the analytic gradient of the two reference expressions).                           */
+int cmvae_reparam_logq_fwd(const float* mean, const float* logvar, const float* eps,
+                           int rows, int M, float* z, float* logq, void* stream);
+int cmvae_reparam_logq_bwd(const float* logvar, const float* eps, const float* gz, const float* glogq,
+                           int rows, int M, float* dmean, float* dlogvar, void* stream);
+
+/* ---- acyclicity: h = tr(expm(A∘A)) - 64 and G = dh/dA = expm(A∘A)^T ∘ 2A
+ * (GMVAE.h_a, omniglot/model.py:159-166).  A [64,64]; h [1]; grad [64,64] (may be NULL). */
+int cmvae_expm_trace(const float* A, float* h, float* grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMVAE_ABI_H */

@@ -1,0 +1,221 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle on the same seeded inputs.
+Tolerance: 1e-4 relative (north_star, fp32); labels bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_pair, clustered_latents, rel_err, RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _causal_desc(model, device):
+    model.to(device)
+    return model._causal_desc()
+
+
+@pytest.mark.parametrize('linear', [False, True])
+def test_causal_rows_and_prior_term(device, linear):
+    from cmvae_amd import ops
+    model, oracle = build_pair('omniglot', linear=linear)
+    c = _causal_desc(model, device)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 64, generator=g)
+    pi = torch.rand(37, generator=g) + 0.1
+    tau = torch.rand(37, generator=g) + 0.5
+    eps, logw = ops.causal_rows(x.to(device), c, pi.to(device), tau.to(device))
+    ref_eps = oracle._causal(x)
+    ref_logw = torch.log(pi) + oracle._glp(ref_eps, torch.log(tau)[:, None].repeat(1, 64))
+    assert rel_err(eps, ref_eps) < 1e-5
+    assert rel_err(logw, ref_logw) < 1e-5
+
+
+@pytest.mark.parametrize('linear', [False, True])
+def test_gram_inverse(device, linear):
+    from cmvae_amd import ops
+    model, oracle = build_pair('omniglot', linear=linear)
+    c = _causal_desc(model, device)
+    I = torch.eye(64)
+    # shared (tau = 1) matrix
+    out = ops.gram_inverse(c, None, 1.0, 1)
+    C = oracle._causal(I)
+    ref = torch.inverse(I + C @ C.T)
+    assert rel_err(out[0], ref) < 1e-5
+    # per-component: C rows = causal(diag(exp(.5 lv)) * tau)
+    g = torch.Generator().manual_seed(5)
+    lv = torch.randn(2, 3, 64, generator=g) * 0.5
+    out = ops.gram_inverse(c, lv.to(device), 0.7)
+    std = torch.diag_embed((0.5 * lv).exp()) * 0.7
+    Cb = oracle._causal(std.view(2, -1, 64)).view(std.shape)
+    ref = torch.inverse(I[None, None] + Cb.matmul(Cb.transpose(-1, -2)))
+    assert rel_err(out.view(2, 3, 64, 64), ref) < 1e-5
+    # it really is the inverse (fp64 check, independent of the oracle's LU)
+    Mx = (I[None, None] + Cb.matmul(Cb.transpose(-1, -2))).double()
+    resid = (out.view(2, 3, 64, 64).double().cpu() @ Mx - torch.eye(64, dtype=torch.float64)).abs().max()
+    assert resid < 1e-4
+
+
+@pytest.mark.parametrize('K,N,linear,gamma,fix_pi', [(3, 96, False, 1, False), (5, 200, True, 1, False),
+                                                       (20, 333, False, 1, False), (20, 1000, False, 4, True),
+                                                       (1, 70, False, 1, False)])
+def test_unsup_prior_trajectory(device, K, N, linear, gamma, fix_pi):
+    """EM parameters after 0,1,..,iters iterations against the oracle's literal loop."""
+    from cmvae_amd import ops
+    B = 3
+    model, oracle = build_pair('omniglot', K=K, linear=linear, gamma=gamma, fix_pi=fix_pi)
+    c = _causal_desc(model, device)
+    z, _, _ = clustered_latents(B, N, K, seed=K + N)
+    rng = np.random.RandomState(7)
+    idx = np.stack([rng.choice(N, K, replace=False) for _ in range(B)], 0)
+    traj = []
+    oracle.unsup_prior(z, idx, iters=4, trajectory=traj)
+    zd = z.to(device)
+    idxd = torch.from_numpy(idx).to(device)
+    for it in (0, 1, 2, 4):
+        pi, mu, tau, logw = ops.unsup_prior(zd, idxd, c, it, fix_pi, model.gamma1)
+        rpi, rmu, rtau = traj[it]
+        assert rel_err(mu, rmu) < RTOL, 'mu after %d iterations' % it
+        assert rel_err(pi, rpi) < RTOL
+        assert rel_err(tau, rtau) < 1e-6
+        rlogw = torch.log(rpi) + oracle._glp(oracle._causal(rmu), torch.log(rtau)[:, :, None].repeat(1, 1, 64))
+        assert rel_err(logw, rlogw) < RTOL
+
+
+def test_unsup_outlier_seed_stays_finite(device):
+    """A far-outlier seed (component that owns a single point) stays finite and matches the oracle.
+    (An exactly-zero N_k — the 1e-22 guard of omniglot/model.py:193 — needs every responsibility
+    of a component to underflow; the guard is applied literally in em_finalize_kernel.)"""
+    from cmvae_amd import ops
+    model, oracle = build_pair('omniglot', K=2, linear=True)
+    with torch.no_grad():
+        model.causal.A.zero_()
+        oracle.P['causal.A'].zero_()
+    c = _causal_desc(model, device)
+    g = torch.Generator().manual_seed(23)
+    z = torch.randn(1, 64, 64, generator=g) * 0.01
+    z[0, 0] = 30.0
+    idx = np.array([[1, 0]])
+    traj = []
+    oracle.unsup_prior(z, idx, iters=2, trajectory=traj)
+    pi, mu, tau, logw = ops.unsup_prior(z.to(device), torch.from_numpy(idx).to(device), c, 2, False, 1.0)
+    assert torch.isfinite(mu).all() and torch.isfinite(pi).all() and torch.isfinite(logw).all()
+    assert rel_err(mu, traj[2][1]) < RTOL
+    assert rel_err(pi, traj[2][0]) < RTOL
+    # KAT-3: A = 0 => Minv = I/2: the outlier component's mean is half the outlier
+    assert abs(float(mu[0, 1, 0]) - 15.0) < 1e-3
+
+
+@pytest.mark.parametrize('K,Nu,Ns,linear,gamma', [(3, 120, 24, False, 1), (5, 300, 40, True, 1),
+                                                   (20, 480, 160, False, 1), (5, 200, 65, False, 2)])
+def test_semi_prior_trajectory(device, K, Nu, Ns, linear, gamma):
+    from cmvae_amd import ops
+    B = 2
+    model, oracle = build_pair('omniglot', K=K, linear=linear, gamma=gamma)
+    c = _causal_desc(model, device)
+    z, lab, _ = clustered_latents(B, Nu + Ns, K, seed=K + Nu)
+    uz, sz = z[:, :Nu].contiguous(), z[:, Nu:].contiguous()
+    y = lab[:, Nu:].contiguous()
+    y[:, :K] = torch.arange(K)        # every class has at least one labeled sample
+    yoh = torch.nn.functional.one_hot(y, K).float()
+    traj = []
+    oracle.semi_prior(uz, sz, yoh, iters=3, trajectory=traj)
+    for it in (0, 1, 3):
+        pi, mu, lv, tau, logw = ops.semi_prior(uz.to(device), sz.to(device), y.to(device), K, c, it, model.gamma1)
+        rpi, rmu, rlv, rtau = traj[it]
+        assert rel_err(mu, rmu) < RTOL, 'mu after %d iterations' % it
+        assert rel_err(lv, rlv) < 5 * RTOL, 'logvar after %d iterations' % it   # log of a small variance
+        assert rel_err(lv.exp(), rlv.exp()) < RTOL
+        assert rel_err(pi, rpi) < 1e-6 and rel_err(tau, rtau) < 1e-6
+
+
+@pytest.mark.parametrize('K,te,M', [(3, 7, 4), (5, 75, 32), (20, 30, 32), (5, 9, 256), (4, 11, 10)])
+def test_posterior_argmax_bit_exact(device, K, te, M):
+    from cmvae_amd import ops
+    B = 2
+    model, oracle = build_pair('omniglot', K=K, M=M)
+    z, lab, centres = clustered_latents(B, te * M, K, seed=te)
+    g = torch.Generator().manual_seed(9)
+    mu = centres + 0.1 * torch.randn(B, K, 64, generator=g)
+    lv = torch.randn(B, K, 64, generator=g) * 0.3
+    logw = torch.randn(B, K, generator=g)
+    y, post = ops.posterior_argmax(z.to(device), mu.to(device), lv.to(device), logw.to(device), te, M, want_post=True)
+    ll = oracle._glp(z.view(B, te, M, 64)[:, :, :, None, :].repeat(1, 1, 1, K, 1),
+                     mu[:, None, None].repeat(1, te, M, 1, 1), lv[:, None, None].repeat(1, te, M, 1, 1)) \
+        + logw[:, None, None, :]
+    ref = torch.exp(ll - torch.logsumexp(ll, -1, keepdim=True)).mean(-2)
+    assert rel_err(post, ref) < RTOL
+    assert torch.equal(y.cpu(), ref.argmax(-1))
+
+
+@pytest.mark.parametrize('K,N', [(3, 50), (20, 700), (5, 64)])
+def test_mixture_loglik_fwd_bwd(device, K, N):
+    from cmvae_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(B, N, 64, generator=g)
+    mu = torch.randn(B, K, 64, generator=g)
+    logw = torch.randn(B, K, generator=g)
+    up = torch.randn(B, N, generator=g)
+    zr = z.clone().double().requires_grad_(True)
+    lr = logw.clone().double().requires_grad_(True)
+    ll = (-0.5 * (zr[:, :, None, :] - mu.double()[:, None]).pow(2) - 0.5 * np.log(2 * np.pi)).sum(-1) + lr[:, None, :]
+    ref = torch.logsumexp(ll, -1)
+    (ref * up.double()).sum().backward()
+    zd = z.to(device).requires_grad_(True)
+    ld = logw.to(device).requires_grad_(True)
+    out = ops.mixture_loglik(zd, mu.to(device), ld)
+    (out * up.to(device)).sum().backward()
+    assert rel_err(out, ref) < 1e-5
+    assert rel_err(zd.grad, zr.grad) < 1e-5
+    assert rel_err(ld.grad, lr.grad) < 1e-5
+
+
+def test_reparam_logq_fwd_bwd(device):
+    from cmvae_amd import ops
+    g = torch.Generator().manual_seed(13)
+    mean = torch.randn(3, 5, 64, generator=g)
+    lv = torch.randn(3, 5, 64, generator=g) * 0.5
+    eps = torch.randn(3, 5, 7, 64, generator=g)
+    gz = torch.randn(3, 5, 7, 64, generator=g)
+    gq = torch.randn(3, 5, 7, generator=g)
+    mr = mean.clone().double().requires_grad_(True)
+    lr = lv.clone().double().requires_grad_(True)
+    zr = eps.double() * (0.5 * lr).exp()[:, :, None] + mr[:, :, None]
+    qr = (-0.5 * (lr[:, :, None] + (zr - mr[:, :, None]).pow(2) / lr.exp()[:, :, None])
+          - 0.5 * np.log(2 * np.pi)).sum(-1)
+    ((zr * gz.double()).sum() + (qr * gq.double()).sum()).backward()
+    md = mean.to(device).requires_grad_(True)
+    ld = lv.to(device).requires_grad_(True)
+    z, q = ops.reparam_logq(md, ld, eps.to(device))
+    ((z * gz.to(device)).sum() + (q * gq.to(device)).sum()).backward()
+    assert rel_err(z, zr) < 1e-6 and rel_err(q, qr) < 1e-5
+    assert rel_err(md.grad, mr.grad) < 1e-5 and rel_err(ld.grad, lr.grad) < 1e-5
+
+
+@pytest.mark.parametrize('scale', [0.0, 0.03, 0.3, 0.5])
+def test_expm_trace(device, scale):
+    """h and dh/dA against fp64 torch.matrix_exp (the fp32 oracle itself loses ~1e-5 absolute to
+    the `trace - 64` cancellation, SURVEY.md §7 'h cancellation')."""
+    from cmvae_amd import ops
+    g = torch.Generator().manual_seed(17)
+    A = torch.randn(64, 64, generator=g) * scale
+    Ar = A.clone().double().requires_grad_(True)
+    href = torch.trace(torch.matrix_exp(Ar * Ar)) - 64
+    href.backward()
+    Ad = A.to(device).requires_grad_(True)
+    h = ops.expm_trace(Ad)
+    h.backward()
+    assert abs(float(h.detach()) - float(href.detach())) <= 1e-5 * max(abs(float(href)), 1e-12) + 1e-12
+    if scale > 0:
+        assert rel_err(Ad.grad, Ar.grad) < 1e-5
+    else:
+        assert float(Ad.grad.abs().max()) == 0.0
+    # the fp32 oracle agrees to its own rounding
+    h32 = torch.trace(torch.matrix_exp(A * A)) - 64
+    assert abs(float(h.detach()) - float(h32)) <= 1e-4 * abs(float(href)) + 64 * 6e-8 * 8
+
+
+def test_missing_gpu_tensor_raises(device):
+    from cmvae_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.mixture_loglik(torch.zeros(1, 4, 64), torch.zeros(1, 2, 64), torch.zeros(1, 2))
