@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py — CMVAE episodic hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+Workload (BASELINE.json metric "train episodes/sec + eval EM episodes/sec, Omniglot 20-way"):
+Omniglot 20-way training step — meta-batch of 4 episodes per GPU, sample-size 300, 32 MC samples,
+10 unsupervised EM iterations, conv VAE + NOTEARS-MLP causal layer, Adam(lr 1e-3, wd 5e-5) —
+i.e. the reference's `python main.py --way 20 --sample-size 300` step (omniglot/trainer.py:79-95).
+One "step" = forward + backward + gradient all-reduce + optimizer step over one synthetic
+meta-batch that is already resident in HBM.  Weak scaling: per-GPU work fixed.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WAY, SAMPLE, MC, B_PER_GPU, EM_ITERS, QUERY = 20, 300, 32, 4, 10, 15
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
+
+
+def synth_images(n, s, device, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return (torch.rand(n, s, 1, 28, 28, generator=g) < 0.15).float().to(device)
+
+
+def build_model(device):
+    from cmvae_amd.model import OmniglotGMVAE
+    torch.manual_seed(10086)
+    m = OmniglotGMVAE(input_shape=[1, 28, 28], unsupervised_em_iters=EM_ITERS, semisupervised_em_iters=EM_ITERS,
+                      fix_pi=False, hidden_size=64, component_size=WAY, latent_size=64,
+                      train_mc_sample_size=MC, test_mc_sample_size=MC)
+    return m.to(device)
+
+
+def event_time_ms(fn, iters, stream):
+    """Average duration of fn() measured with HIP events on the stream the kernels run on."""
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    start.record(stream)
+    for _ in range(iters):
+        fn()
+    end.record(stream)
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def roofline_em_pass(device):
+    """Dominant hand-written HBM-bound kernel: the fused E-step/M-step pass (em_pass_kernel).
+    Algorithmic bytes per launch = B*(N*D*4 + K*(2D+2)*4)  (SURVEY.md §8d)."""
+    from cmvae_amd import ops
+    B, N, K, D = B_PER_GPU, SAMPLE * MC, WAY, 64
+    g = torch.Generator(device='cpu').manual_seed(1)
+    z = torch.randn(B, N, D, generator=g).to(device)
+    mu = torch.randn(B, K, D, generator=g).to(device)
+    logw = torch.randn(B, K, generator=g).to(device)
+    ws, _ = ops.em_pass(z, mu, logw)
+    stream = torch.cuda.current_stream()
+    ms = event_time_ms(lambda: ops.em_pass(z, mu, logw, ws), 200, stream)
+    alg_bytes = B * (N * D * 4 + K * (2 * D + 2) * 4)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return {'kernel': 'em_pass_kernel', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+            'launch_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes}
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (a restatement of the reference's PyTorch op sequence) on the same workload,
+    bounded to ONE training step of 4 episodes (about 10-30 s of CPU work)."""
+    from cmvae_amd.model import OmniglotGMVAE
+    from oracle.gmvae_oracle import OracleGMVAE, make_trainable, train_step
+    torch.set_num_threads(threads)
+    torch.manual_seed(10086)
+    np.random.seed(10086)
+    m = OmniglotGMVAE(unsupervised_em_iters=EM_ITERS, semisupervised_em_iters=EM_ITERS, component_size=WAY,
+                      train_mc_sample_size=MC, test_mc_sample_size=MC)
+    P = make_trainable({k: v.detach().clone() for k, v in m.state_dict().items()})
+    oracle = OracleGMVAE(P, 'omniglot', unsupervised_em_iters=EM_ITERS, semisupervised_em_iters=EM_ITERS,
+                         component_size=WAY, train_mc_sample_size=MC, test_mc_sample_size=MC)
+    opt = torch.optim.Adam([p for p in P.values() if p.requires_grad], lr=1e-3, weight_decay=5e-5)
+    X = synth_images(B_PER_GPU, SAMPLE, 'cpu', 7)
+    # tiny warm-up (thread pool, allocator) on 1 episode of 20 items; not part of the sample
+    small = OracleGMVAE(P, 'omniglot', unsupervised_em_iters=1, component_size=WAY, train_mc_sample_size=2)
+    small.forward(X[:1, :24], 0.1, 0.1, 1e-4)
+    t0 = time.perf_counter()
+    train_step(oracle, opt, X, 0.1, 0.1, 1e-4)
+    dt = time.perf_counter() - t0
+    return {'value': round(B_PER_GPU / dt, 4), 'unit': 'train episodes/s', 'cores': threads, 'kind': 'port',
+            'sample': '1 training step (4 episodes) of the same Omniglot 20-way workload, oracle/gmvae_oracle.py',
+            'seconds': round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eval-calls', type=int, default=10)
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+    from cmvae_amd import dist as cdist
+    rank, world = cdist.init_from_env()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run' % args.gpus)
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    model = build_model(device)
+    flat = cdist.FlatGrads(model.parameters())
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+    except Exception:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+    np.random.seed(10086)
+    torch.manual_seed(10086 + rank)
+
+    # synthetic meta-batches, resident in HBM before the timed region; each rank owns its shard
+    n_pool = 4
+    pool = [synth_images(B_PER_GPU * world, SAMPLE, 'cpu', 100 + i)[cdist.shard_slice(B_PER_GPU * world, rank, world)]
+            .to(device) for i in range(n_pool)]
+    h_lambda, h_c, a_lambda = 0.1, 0.1, 1e-4
+    N = SAMPLE * MC
+
+    def step(i):
+        model.train()
+        flat.zero()
+        X = pool[i % n_pool]
+        idx = torch.from_numpy(cdist.draw_em_init(N, WAY, B_PER_GPU * world, rank, world)).to(device)
+        _, rec, kl, h_aug, _ = model(X, h_lambda, h_c, a_lambda, init_idx=idx)
+        (rec + kl + h_aug).backward()
+        flat.allreduce()
+        opt.step()
+        return rec, kl, h_aug
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def note(msg):
+        if rank == 0:
+            print('[bench %7.1fs] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    for i in range(args.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        note('warmup step %d done' % i)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(i)
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    losses = [float(x) for x in last]
+    note('timed region done: %.2f ms/step' % (dt / args.steps * 1e3))
+    ms_per_step = dt / args.steps * 1e3
+    train_eps = B_PER_GPU * world * args.steps / dt
+
+    # eval: GMVAE.prediction, 20-way, B=4 episodes per call (reference default), query 15
+    eval_rates = {}
+    model.eval()
+    for shot in (1, 5):
+        tr, te = WAY * shot, WAY * QUERY
+        Xtr = synth_images(B_PER_GPU, tr, device, 200 + shot)
+        Xte = synth_images(B_PER_GPU, te, device, 300 + shot)
+        ytr = torch.arange(WAY, device=device).repeat_interleave(shot)[None].repeat(B_PER_GPU, 1)
+        for _ in range(2):
+            model.prediction(Xtr, ytr, Xte)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.eval_calls):
+            y = model.prediction(Xtr, ytr, Xte)
+        barrier()
+        torch.cuda.synchronize()
+        edt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([edt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            edt = float(t)
+        eval_rates['%dshot' % shot] = round(B_PER_GPU * world * args.eval_calls / edt, 2)
+        note('eval %d-shot done' % shot)
+
+    if rank == 0:
+        out = {
+            'metric': 'train episodes/sec (whole node) + eval EM episodes/sec, Omniglot 20-way',
+            'value': round(train_eps, 3), 'unit': 'train episodes/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'Omniglot 20-way train step: 4 episodes/GPU x sample-size 300 x 32 MC, '
+                                   '10 EM iters, conv VAE + NOTEARS-MLP causal, Adam (configs[2]; the metric\'s config)',
+                       'global_batch_episodes': B_PER_GPU * world, 'parallelism': 'dp%d' % world},
+            'eval_episodes_per_s': eval_rates,
+            'final_losses': {'rec': losses[0], 'kl': losses[1], 'h_aug': losses[2]},
+        }
+        out['roofline'] = roofline_em_pass(device)
+        note('roofline micro-measure done; starting cpu baseline')
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '16')))
+            cb = cpu_baseline(threads)
+            out['cpu_baseline'] = cb
+            out['speedup_vs_cpu'] = round(train_eps / cb['value'], 1)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

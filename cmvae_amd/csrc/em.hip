@@ -779,6 +779,20 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
     return 0;
 }
 
+extern "C" int cmvae_em_pass(const float* z, const float* mu, const float* logw, int B, int N, int K, void* workspace,
+                             size_t workspace_bytes, int* nblk_out, void* stream) {
+    CMVAE_REQUIRE(z && mu && logw, "cmvae_em_pass: NULL tensor");
+    CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_em_pass: bad shape");
+    EmWorkspace w = carve(workspace, B, N, 0, K, false);
+    CMVAE_REQUIRE(workspace && workspace_bytes >= w.bytes, "cmvae_em_pass: workspace %zu < %zu", workspace_bytes,
+                  w.bytes);
+    PassArgs p{};
+    p.z = z; p.mu = mu; p.logw = logw; p.part_N = w.part_N; p.part_S1 = w.part_S1;
+    p.N = N; p.K = K; p.tiles_per_block = pick_tiles_per_block(B, N); p.nblk = nblk_for(N, p.tiles_per_block);
+    if (nblk_out) *nblk_out = p.nblk;
+    return launch_pass(p, B, (hipStream_t)stream);
+}
+
 extern "C" size_t cmvae_semi_prior_workspace_bytes(int B, int Nu, int Ns, int K) {
     return carve(nullptr, B, Nu, Ns, K, true).bytes;
 }

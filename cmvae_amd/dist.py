@@ -93,7 +93,8 @@ class _SyncBN(torch.autograd.Function):
         stats[:C] = x.sum(red)
         stats[C:2 * C] = (x * x).sum(red)
         stats[2 * C] = x.numel() // C
-        tdist.all_reduce(stats, op=tdist.ReduceOp.SUM)
+        if world_size() > 1:
+            tdist.all_reduce(stats, op=tdist.ReduceOp.SUM)
         n = stats[2 * C]
         mean = stats[:C] / n
         var = stats[C:2 * C] / n - mean * mean
@@ -112,7 +113,8 @@ class _SyncBN(torch.autograd.Function):
         local[:C] = dy.sum(red)
         local[C:] = (dy * xhat).sum(red)
         dbias, dweight = local[:C].clone(), local[C:].clone()
-        tdist.all_reduce(local, op=tdist.ReduceOp.SUM)
+        if world_size() > 1:
+            tdist.all_reduce(local, op=tdist.ReduceOp.SUM)
         mdy = (local[:C] / n).view(1, C, 1, 1)
         mdyx = (local[C:] / n).view(1, C, 1, 1)
         dx = (weight * invstd).view(1, C, 1, 1) * (dy - mdy - xhat * mdyx)

@@ -29,13 +29,38 @@ class EpisodeBatchNorm2d(nn.BatchNorm2d):
     """
 
     def forward(self, x):
-        if self.training and _dist.world_size() > 1:
+        if self.training:
             return _dist.sync_batch_norm(x, self)
-        return super().forward(x)
+        C = x.shape[1]
+        scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+        shift = self.bias - self.running_mean * scale
+        return x * scale.view(1, C, 1, 1) + shift.view(1, C, 1, 1)
+
+
+class GemmConv2d(nn.Conv2d):
+    """3x3 / stride 1 / pad 1 convolution as im2col + GEMM (no JIT-compiled library kernels)."""
+
+    def forward(self, x):
+        n, _, h, w = x.shape
+        cols = F.unfold(x, 3, padding=1)                               # [n, cin*9, h*w]
+        out = self.weight.view(self.out_channels, -1).matmul(cols)      # [n, cout, h*w]
+        return out.view(n, self.out_channels, h, w) + self.bias.view(1, -1, 1, 1)
+
+
+class GemmConvTranspose2d(nn.ConvTranspose2d):
+    """k x k / stride 2 / pad 1 transposed convolution as GEMM + col2im."""
+
+    def forward(self, x):
+        n, cin, h, w = x.shape
+        k = self.kernel_size[0]
+        ho, wo = (h - 1) * 2 - 2 + k, (w - 1) * 2 - 2 + k
+        cols = self.weight.view(cin, -1).t().matmul(x.reshape(n, cin, h * w))   # [n, cout*k*k, h*w]
+        out = F.fold(cols, (ho, wo), k, padding=1, stride=2)
+        return out + self.bias.view(1, -1, 1, 1)
 
 
 def _conv_block(cin, cout):
-    return [nn.Conv2d(cin, cout, 3, 1, 1), EpisodeBatchNorm2d(cout), nn.ReLU(inplace=True),
+    return [GemmConv2d(cin, cout, 3, 1, 1), EpisodeBatchNorm2d(cout), nn.ReLU(inplace=True),
             nn.MaxPool2d(2, ceil_mode=True)]
 
 
@@ -62,10 +87,10 @@ class OmniglotDecoder(nn.Module):
         self.hidden_size = hidden_size
         h = hidden_size
         self.decoder = nn.Sequential(
-            nn.ConvTranspose2d(h, h, 4, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
-            nn.ConvTranspose2d(h, h, 3, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
-            nn.ConvTranspose2d(h, h, 4, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
-            nn.ConvTranspose2d(h, 1, 4, 2, 1), nn.Sigmoid())
+            GemmConvTranspose2d(h, h, 4, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
+            GemmConvTranspose2d(h, h, 3, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
+            GemmConvTranspose2d(h, h, 4, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
+            GemmConvTranspose2d(h, 1, 4, 2, 1), nn.Sigmoid())
 
     def forward(self, h):
         return self.decoder(h.view(-1, self.hidden_size, 2, 2))

@@ -109,6 +109,18 @@ def unsup_prior(z, init_idx, causal, iters, fix_pi=False, gamma1=1.0):
     return pi, mu, tau, logw
 
 
+def em_pass(z, mu, logw, ws=None):
+    """One fused E-step + M-step pass (partials left in the workspace); for measurement and tests."""
+    B, N, K = _mix_shapes(z, mu, logw)
+    ws_bytes = lib.cmvae_unsup_prior_workspace_bytes(B, N, K)
+    if ws is None:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=z.device)
+    nblk = ctypes.c_int(0)
+    check(lib.cmvae_em_pass(_p(z), _p(mu), _p(logw), B, N, K, _p(ws), ws.numel(), ctypes.byref(nblk), _stream()),
+          'cmvae_em_pass')
+    return ws, nblk.value
+
+
 def semi_prior(uz, sz, y, K, causal, iters, gamma1=1.0):
     """GMVAE.get_semisupervised_prior: returns (pi, mu, logvar, tau, logw)."""
     uz = _req(uz, 'unsupervised_z'); sz = _req(sz, 'supervised_z'); y = _req(y, 'y', torch.int64)

@@ -77,6 +77,13 @@ int cmvae_unsup_prior(const float* z, int B, int N, int K, const int64_t* init_i
                       void* workspace, size_t workspace_bytes,
                       float* pi, float* mu, float* tau, float* logw, void* stream);
 
+/* ---- one fused E-step + M-step pass over z (the loop body's hot kernel, exposed for
+ * measurement and tests): responsibilities from (mu, logw) and per-block partial sums
+ * part_N [B,nblk,32], part_S1 [B,nblk,K,64] in `workspace` (layout of cmvae_unsup_prior).
+ * Returns nblk through *nblk_out.  omniglot/model.py:173-193, 213-218.                     */
+int cmvae_em_pass(const float* z, const float* mu, const float* logw, int B, int N, int K,
+                  void* workspace, size_t workspace_bytes, int* nblk_out, void* stream);
+
 /* ---- semi-supervised EM prior: GMVAE.get_semisupervised_prior (omniglot/model.py:370-412)
  * with get_semisupervised_params (224-330) as the loop body.
  * uz [B,Nu,64] unlabeled latents, sz [B,Ns,64] labeled latents, y [B,Ns] int64 labels in
