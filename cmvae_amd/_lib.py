@@ -22,6 +22,18 @@ class CausalDesc(ctypes.Structure):
 
 _PC = ctypes.POINTER(CausalDesc)
 
+
+class ConvGeom(ctypes.Structure):
+    """struct cmvae_conv_geom (include/cmvae_abi.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ('rows_total', 'Hg', 'Wg', 'Hi', 'Wi', 'sy', 'sx', 'Ho', 'Wo', 'oys',
+                                              'oxs', 'oy0', 'ox0', 'ntaps', 'a_pitch', 'o_pitch', 'w_pitch')] + \
+               [('w_tap_stride', ctypes.c_int64), ('w_nblk_stride', ctypes.c_int64),
+                ('dy', ctypes.c_int32 * 16), ('dx', ctypes.c_int32 * 16), ('a_col', ctypes.c_int32 * 16)]
+
+
+_PG = ctypes.POINTER(ConvGeom)
+c_int64 = ctypes.c_int64
+
 # name -> (restype, argtypes); must list every symbol of include/cmvae_abi.h
 SIGNATURES = {
     'cmvae_last_error': (ctypes.c_char_p, []),
@@ -46,6 +58,13 @@ SIGNATURES = {
     'cmvae_reparam_logq_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p]),
     'cmvae_expm_trace': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_conv_gemm_grid': (c_int, [c_int, c_int]),
+    'cmvae_conv_gemm': (c_int, [_PG, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                c_void_p, c_void_p]),
+    'cmvae_conv_wgrad_workspace_bytes': (c_size_t, [c_int]),
+    'cmvae_conv_wgrad': (c_int, [_PG, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 ctypes.POINTER(c_int64), c_int64, c_int64, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_size_t, c_void_p]),
 }
 
 

@@ -1,0 +1,115 @@
+"""Host side of the fp32-MFMA gather-GEMM family (csrc/conv_gemm.hip): geometry builders for
+conv 3x3, the sub-pixel phases of the stride-2 transposed convs, their data gradients and
+nn.Linear, plus thin wrappers over cmvae_conv_gemm / cmvae_conv_wgrad.
+
+All activations are channels-last matrices [pixels, C] (C = 64 in the conv stacks).
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, check, ConvGeom
+
+_p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _geom(rows, Hg, Wg, Hi, Wi, sy, sx, Ho, Wo, oys, oxs, oy0, ox0, taps, a_pitch, o_pitch, w_pitch, w_tap_stride,
+          w_nblk_stride=0, a_cols=None):
+    g = ConvGeom()
+    g.rows_total, g.Hg, g.Wg, g.Hi, g.Wi, g.sy, g.sx = rows, Hg, Wg, Hi, Wi, sy, sx
+    g.Ho, g.Wo, g.oys, g.oxs, g.oy0, g.ox0 = Ho, Wo, oys, oxs, oy0, ox0
+    g.ntaps = len(taps)
+    g.a_pitch, g.o_pitch, g.w_pitch = a_pitch, o_pitch, w_pitch
+    g.w_tap_stride, g.w_nblk_stride = w_tap_stride, w_nblk_stride
+    for t, (dy, dx) in enumerate(taps):
+        g.dy[t], g.dx[t] = dy, dx
+        g.a_col[t] = 0 if a_cols is None else a_cols[t]
+    return g
+
+
+def geom_conv3x3(n, H, W, transpose=False, C=64):
+    """3x3 / stride 1 / pad 1 conv over [n,H,W,C]; transpose=True gives the data-gradient taps."""
+    taps = [((1 - ky) if transpose else (ky - 1), (1 - kx) if transpose else (kx - 1))
+            for ky in range(3) for kx in range(3)]
+    return _geom(n * H * W, H, W, H, W, 1, 1, H, W, 1, 1, 0, 0, taps, C, C, C, C * C)
+
+
+def convT_out(h, k):
+    return (h - 1) * 2 - 2 + k
+
+
+def convT_phase_taps(k, py, px):
+    """Kernel taps (ky,kx) and source offsets (dy,dx) feeding output pixels of parity (py,px)."""
+    out = []
+    for ky in range(k):
+        if (py + 1 - ky) % 2:
+            continue
+        for kx in range(k):
+            if (px + 1 - kx) % 2:
+                continue
+            out.append((ky, kx, (py + 1 - ky) // 2, (px + 1 - kx) // 2))
+    return out
+
+
+def geom_convT_phase(n, Hi, Wi, k, py, px, C=64):
+    """One sub-pixel phase of ConvTranspose2d(k, stride 2, pad 1): [n,Hi,Wi,C] -> [n,Ho,Wo,C]."""
+    Ho, Wo = convT_out(Hi, k), convT_out(Wi, k)
+    Hg, Wg = (Ho - py + 1) // 2, (Wo - px + 1) // 2
+    taps = convT_phase_taps(k, py, px)
+    g = _geom(n * Hg * Wg, Hg, Wg, Hi, Wi, 1, 1, Ho, Wo, 2, 2, py, px, [(t[2], t[3]) for t in taps], C, C, C, C * C)
+    return g, [t[0] * k + t[1] for t in taps]
+
+
+def geom_convT_dgrad(n, Hi, Wi, k, C=64):
+    """Data gradient of the transposed conv = stride-2 conv over d_out [n,Ho,Wo,C] -> [n,Hi,Wi,C]."""
+    Ho, Wo = convT_out(Hi, k), convT_out(Wi, k)
+    taps = [(ky - 1, kx - 1) for ky in range(k) for kx in range(k)]
+    return _geom(n * Hi * Wi, Hi, Wi, Ho, Wo, 2, 2, Hi, Wi, 1, 1, 0, 0, taps, C, C, C, C * C)
+
+
+def geom_linear(rows, K, N, a_pitch=None, o_pitch=None):
+    """y = x @ W^T with W [N,K] (torch layout); K, N multiples of 64, K <= 1024."""
+    assert K % 64 == 0 and N % 64 == 0 and K // 64 <= 16
+    taps = [(0, 0)] * (K // 64)
+    return _geom(rows, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, taps, a_pitch or K, o_pitch or N, K, 64, 64 * K,
+                 a_cols=[64 * t for t in range(K // 64)])
+
+
+def gemm_grid(rows, ncb=1):
+    return lib.cmvae_conv_gemm_grid(rows, ncb)
+
+
+def conv_gemm(g, A, Wt, out, bias=None, a_scale=None, a_shift=None, act=0, n_col_blocks=1, stats=False):
+    """Launch the forward gather-GEMM.  Returns per-block partial statistics [grid,128] if asked."""
+    part = None
+    if stats:
+        part = torch.empty(gemm_grid(g.rows_total, 1), 128, device=A.device, dtype=torch.float32)
+    check(lib.cmvae_conv_gemm(ctypes.byref(g), _p(A), _p(Wt), _p(bias), _p(a_scale), _p(a_shift), act, n_col_blocks,
+                              _p(out), _p(part), _stream()), 'cmvae_conv_gemm')
+    return part
+
+
+_ws_cache = {}
+
+
+def _wgrad_ws(rows, device):
+    nbytes = lib.cmvae_conv_wgrad_workspace_bytes(rows)
+    key = (device, 'wgrad')
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def conv_wgrad(g, A, G, dW, tap_off, s_ci, s_co, db=None, accumulate_db=False, a_scale=None, a_shift=None,
+               g_pitch=64, g_col=0):
+    ws = _wgrad_ws(g.rows_total, A.device)
+    offs = (ctypes.c_int64 * len(tap_off))(*tap_off)
+    check(lib.cmvae_conv_wgrad(ctypes.byref(g), _p(A), _p(a_scale), _p(a_shift), _p(G), g_pitch, g_col, offs,
+                               s_ci, s_co, _p(dW), _p(db), int(accumulate_db), _p(ws), ws.numel(), _stream()),
+          'cmvae_conv_wgrad')

@@ -1,0 +1,412 @@
+// fp32-MFMA gather-GEMM family for the dense contractions of the CMVAE hot path (gfx950).
+//
+// Every activation lives in HBM as a row-major matrix [pixels, C] (channels-last, C = 64 for
+// the conv stacks => one pixel = one 256-B row).  One kernel shape serves conv 3x3, the four
+// sub-pixel phases of a stride-2 transposed conv, their data gradients, and Linear layers:
+//
+//     out[r, 0:64] = act( sum_t  T(A[src(r,t), a_col_t : a_col_t+64]) @ W_t[64x64]  + bias )
+//
+// where r enumerates (image, y, x) over a per-image grid, src(r,t) = (image, y*sy+dy_t,
+// x*sx+dx_t) (zero outside the image) and T is an optional per-channel affine + ReLU (the
+// previous layer's BatchNorm folded into the operand load).  v_mfma_f32_32x32x2_f32 does the
+// math (exact fp32 fma chains); A and W_t tiles are staged through LDS with register prefetch.
+// The weight-gradient kernel contracts over r instead.
+#include "common.h"
+
+namespace cmvae {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;       // rows per block tile
+constexpr int LDA = 68;       // LDS row pitch (floats): 16-B aligned, conflict-free b128 fragment reads
+
+struct ConvGeom {
+    int rows_total;
+    int Hg, Wg;               // per-image grid the rows enumerate
+    int Hi, Wi;               // input image, pixels
+    int sy, sx;               // src = (y*sy + dy_t, x*sx + dx_t)
+    int Ho, Wo;               // output image, pixels
+    int oys, oxs, oy0, ox0;   // out pixel = (y*oys + oy0, x*oxs + ox0)
+    int ntaps;
+    int a_pitch, o_pitch;     // floats per input / output pixel row
+    int w_pitch;              // floats between consecutive output columns of W_t ([col][k] layout)
+    long w_tap_stride;        // floats between taps
+    long w_nblk_stride;       // floats between 64-column output blocks (blockIdx.y)
+    signed char dy[16], dx[16];
+    int a_col[16];
+};
+
+struct RowInfo {
+    int base;                 // image * Hi*Wi
+    int ys, xs;               // y*sy, x*sx
+    bool valid;
+};
+
+__device__ __forceinline__ RowInfo row_info(const ConvGeom& g, int r) {
+    RowInfo ri;
+    ri.valid = r < g.rows_total;
+    const int hw = g.Hg * g.Wg;
+    const int n = r / hw;
+    const int rem = r - n * hw;
+    const int y = rem / g.Wg;
+    const int x = rem - y * g.Wg;
+    ri.base = n * g.Hi * g.Wi;
+    ri.ys = y * g.sy;
+    ri.xs = x * g.sx;
+    return ri;
+}
+
+__device__ __forceinline__ int out_pixel(const ConvGeom& g, int r) {
+    if (r >= g.rows_total) return -1;
+    const int hw = g.Hg * g.Wg;
+    const int n = r / hw;
+    const int rem = r - n * hw;
+    const int y = rem / g.Wg;
+    const int x = rem - y * g.Wg;
+    return (n * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
+}
+
+// Load 4 channels of the source pixel of row `ri` for tap t; *ok says whether the tap is inside the image.
+__device__ __forceinline__ float4 load_a(const ConvGeom& g, const float* __restrict__ A, const RowInfo& ri, int t,
+                                         int q, bool* ok) {
+    const int sy = ri.ys + g.dy[t], sx = ri.xs + g.dx[t];
+    *ok = ri.valid && sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
+    if (!*ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const long pix = (long)ri.base + sy * g.Wi + sx;
+    return *reinterpret_cast<const float4*>(A + pix * g.a_pitch + g.a_col[t] + 4 * q);
+}
+
+// previous layer's BatchNorm + ReLU folded into the operand load; padding stays exactly zero
+__device__ __forceinline__ float4 transform_a(float4 v, bool ok, bool has_t, const float4& sc, const float4& sh) {
+    if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_t) {
+        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+        v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+        v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    }
+    return v;
+}
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return v > 0.f ? v : expm1f(v);
+    return v;
+}
+
+// ---------------------------------------------------------------------------- forward gather-GEMM
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGeom g, const float* __restrict__ A,
+                                                           const float* __restrict__ Wt,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ a_scale,
+                                                           const float* __restrict__ a_shift,
+                                                           float* __restrict__ out, float* __restrict__ stats_part) {
+    __shared__ __align__(16) float As[BM * LDA];
+    __shared__ __align__(16) float Ws[64 * LDA];
+    __shared__ int opix[BM];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int q = tid & 15, rb = tid >> 4;
+    const int nb = blockIdx.y;
+    const float* Wn = Wt + nb * g.w_nblk_stride;
+    const bool has_t = a_scale != nullptr;
+    const int ntiles = (g.rows_total + BM - 1) / BM;
+    float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
+    const float b0 = bias ? bias[nb * 64 + i] : 0.f;
+    const float b1 = bias ? bias[nb * 64 + 32 + i] : 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        RowInfo ri[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ri[e] = row_info(g, tile * BM + rb + 16 * e);
+        if (tid < BM) opix[tid] = out_pixel(g, tile * BM + tid);
+        floatx16 acc0 = {}, acc1 = {};
+        float4 ra[8], rw[4];
+        bool ok[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], 0, q, &ok[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            rw[e] = *reinterpret_cast<const float4*>(Wn + (long)(rb + 16 * e) * g.w_pitch + 4 * q);
+        for (int t = 0; t < g.ntaps; ++t) {
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_t) {
+                sc = *reinterpret_cast<const float4*>(a_scale + g.a_col[t] + 4 * q);
+                sh = *reinterpret_cast<const float4*>(a_shift + g.a_col[t] + 4 * q);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<float4*>(&As[(rb + 16 * e) * LDA + 4 * q]) =
+                    transform_a(ra[e], ok[e], has_t, sc, sh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(&Ws[(rb + 16 * e) * LDA + 4 * q]) = rw[e];
+            __syncthreads();
+            if (t + 1 < g.ntaps) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], t + 1, q, &ok[e]);
+                const float* Wn1 = Wn + (t + 1) * g.w_tap_stride;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    rw[e] = *reinterpret_cast<const float4*>(Wn1 + (long)(rb + 16 * e) * g.w_pitch + 4 * q);
+            }
+            const float* ap = &As[(32 * w + i) * LDA + 4 * h];
+            const float* bp0 = &Ws[i * LDA + 4 * h];
+            const float* bp1 = &Ws[(32 + i) * LDA + 4 * h];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * kk);
+                const float4 p4 = *reinterpret_cast<const float4*>(bp0 + 8 * kk);
+                const float4 r4 = *reinterpret_cast<const float4*>(bp1 + 8 * kk);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, p4.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, r4.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, p4.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, r4.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, p4.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, r4.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, p4.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
+            }
+        }
+        // epilogue: C[row = (reg&3) + 8*(reg>>2) + 4*h][col = i]
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int op = opix[row];
+            if (op >= 0) {
+                const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
+                ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
+                ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
+                float* o = out + (long)op * g.o_pitch + nb * 64;
+                o[i] = apply_act<ACT>(v0);
+                o[32 + i] = apply_act<ACT>(v1);
+            }
+        }
+        __syncthreads();     // opix reused by the next tile
+    }
+    if (stats_part) {
+        ssum0 += __shfl_xor(ssum0, 32); ssum1 += __shfl_xor(ssum1, 32);
+        ssq0 += __shfl_xor(ssq0, 32); ssq1 += __shfl_xor(ssq1, 32);
+        float* red = As;     // [4 waves][128]
+        __syncthreads();
+        if (h == 0) {
+            red[w * 128 + i] = ssum0; red[w * 128 + 32 + i] = ssum1;
+            red[w * 128 + 64 + i] = ssq0; red[w * 128 + 96 + i] = ssq1;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float v = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            stats_part[((long)blockIdx.y * gridDim.x + blockIdx.x) * 128 + tid] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- weight gradient
+// part[blk][t][ci][co] = sum_r T(A[src(r,t)])[ci] * G[outpix(r)][g_col + co]
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0, const float* __restrict__ A,
+                                                            const float* __restrict__ a_scale,
+                                                            const float* __restrict__ a_shift,
+                                                            const float* __restrict__ G, int g_pitch, int g_col,
+                                                            float* __restrict__ part, float* __restrict__ db_part) {
+    __shared__ __align__(16) float As[BM * 64];
+    __shared__ __align__(16) float Gs[BM * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int q = tid & 15, rb = tid >> 4;
+    const int ci_h = w >> 1, co_h = w & 1;
+    const bool has_t = a_scale != nullptr;
+    const int ntiles = (g.rows_total + BM - 1) / BM;
+    floatx16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = floatx16{};
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        RowInfo ri[8];
+        float4 rg[8], ra[8];
+        bool ok[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = tile * BM + rb + 16 * e;
+            ri[e] = row_info(g, r);
+            const int op = out_pixel(g, r);
+            rg[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (op >= 0) rg[e] = *reinterpret_cast<const float4*>(G + (long)op * g_pitch + g_col + 4 * q);
+            dbs.x += rg[e].x; dbs.y += rg[e].y; dbs.z += rg[e].z; dbs.w += rg[e].w;
+            ra[e] = load_a(g, A, ri[e], tap0, q, &ok[e]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<float4*>(&Gs[(rb + 16 * e) * 64 + 4 * q]) = rg[e];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_t) {
+                sc = *reinterpret_cast<const float4*>(a_scale + g.a_col[tap0 + t] + 4 * q);
+                sh = *reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t] + 4 * q);
+            }
+            if (t > 0) __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<float4*>(&As[(rb + 16 * e) * 64 + 4 * q]) =
+                    transform_a(ra[e], ok[e], has_t, sc, sh);
+            __syncthreads();
+            if (t + 1 < NT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tap0 + t + 1, q, &ok[e]);
+            }
+            const float* ap = &As[h * 64 + 32 * ci_h + i];
+            const float* gp = &Gs[h * 64 + 32 * co_h + i];
+#pragma unroll 16
+            for (int rr = 0; rr < BM / 2; ++rr)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[rr * 128], gp[rr * 128], acc[t], 0, 0, 0);
+        }
+    }
+    float* pb = part + (long)blockIdx.x * NT * 4096;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ci = 32 * ci_h + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            pb[t * 4096 + ci * 64 + 32 * co_h + i] = acc[t][reg];
+        }
+    if (db_part) {
+        // column sums of G: thread (rb, q) holds cols 4q..4q+3 over its rows
+        __syncthreads();
+        float* red = As;
+        *reinterpret_cast<float4*>(&red[rb * 64 + 4 * q]) = dbs;
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
+            db_part[(long)blockIdx.x * 64 + tid] = s;
+        }
+    }
+}
+
+// out[tap_off[t] + ci*s_ci + co*s_co] = sum_blk part[blk][t][ci][co];  db[co] = sum_blk db_part[blk][co]
+struct WgradOut {
+    long tap_off[4];
+    long s_ci, s_co;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nblk, int NT,
+                                                           WgradOut o, float* __restrict__ dW,
+                                                           const float* __restrict__ db_part,
+                                                           float* __restrict__ db, int accumulate_db) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < NT * 4096) {
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += part[(long)b * NT * 4096 + e];
+        const int t = e >> 12, ci = (e >> 6) & 63, co = e & 63;
+        dW[o.tap_off[t] + ci * o.s_ci + co * o.s_co] = s;
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x < 64) {
+        float s = 0.f;
+        for (int b = 0; b < nblk; ++b) s += db_part[(long)b * 64 + threadIdx.x];
+        if (accumulate_db) s += db[threadIdx.x];
+        db[threadIdx.x] = s;
+    }
+}
+
+static int check_geom(const ConvGeom& g) {
+    CMVAE_REQUIRE(g.rows_total >= 0 && g.Hg > 0 && g.Wg > 0 && g.Hi > 0 && g.Wi > 0 && g.Ho > 0 && g.Wo > 0,
+                  "conv geometry: non-positive extent");
+    CMVAE_REQUIRE(g.ntaps >= 1 && g.ntaps <= 16, "conv geometry: ntaps=%d outside [1,16]", g.ntaps);
+    CMVAE_REQUIRE(g.a_pitch >= 64 && g.a_pitch % 4 == 0 && g.o_pitch >= 64, "conv geometry: bad pitch");
+    CMVAE_REQUIRE(g.rows_total % (g.Hg * g.Wg) == 0, "conv geometry: rows not a multiple of the per-image grid");
+    CMVAE_REQUIRE((g.Hg - 1) * g.oys + g.oy0 < g.Ho && (g.Wg - 1) * g.oxs + g.ox0 < g.Wo && g.oy0 >= 0 && g.ox0 >= 0,
+                  "conv geometry: output grid exceeds the output image");
+    for (int t = 0; t < g.ntaps; ++t)
+        CMVAE_REQUIRE(g.a_col[t] >= 0 && g.a_col[t] + 64 <= g.a_pitch && g.a_col[t] % 4 == 0,
+                      "conv geometry: tap %d column window outside the input row", t);
+    return 0;
+}
+
+}  // namespace cmvae
+
+using namespace cmvae;
+
+static ConvGeom to_geom(const cmvae_conv_geom* c) {
+    ConvGeom g{};
+    g.rows_total = c->rows_total; g.Hg = c->Hg; g.Wg = c->Wg; g.Hi = c->Hi; g.Wi = c->Wi; g.sy = c->sy; g.sx = c->sx;
+    g.Ho = c->Ho; g.Wo = c->Wo; g.oys = c->oys; g.oxs = c->oxs; g.oy0 = c->oy0; g.ox0 = c->ox0; g.ntaps = c->ntaps;
+    g.a_pitch = c->a_pitch; g.o_pitch = c->o_pitch; g.w_pitch = c->w_pitch; g.w_tap_stride = c->w_tap_stride;
+    g.w_nblk_stride = c->w_nblk_stride;
+    for (int t = 0; t < 16; ++t) { g.dy[t] = (signed char)c->dy[t]; g.dx[t] = (signed char)c->dx[t]; g.a_col[t] = c->a_col[t]; }
+    return g;
+}
+
+static int gemm_grid(int rows_total, int nblk_cols) {
+    const int ntiles = (rows_total + BM - 1) / BM;
+    int gx = 512 / (nblk_cols > 0 ? nblk_cols : 1);
+    if (gx < 64) gx = 64;
+    return ntiles < gx ? (ntiles > 0 ? ntiles : 1) : gx;
+}
+
+extern "C" int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks) { return gemm_grid(rows_total, n_col_blocks); }
+
+extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, const float* Wt, const float* bias,
+                               const float* a_scale, const float* a_shift, int act, int n_col_blocks, float* out,
+                               float* stats_part, void* stream) {
+    CMVAE_REQUIRE(geom && A && Wt && out, "cmvae_conv_gemm: NULL argument");
+    CMVAE_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "cmvae_conv_gemm: scale and shift go together");
+    CMVAE_REQUIRE(n_col_blocks >= 1 && act >= 0 && act <= 2, "cmvae_conv_gemm: bad act / column blocks");
+    ConvGeom g = to_geom(geom);
+    if (int e = check_geom(g)) return e;
+    CMVAE_REQUIRE(g.o_pitch >= 64 * n_col_blocks, "cmvae_conv_gemm: output pitch < columns");
+    CMVAE_REQUIRE(!stats_part || n_col_blocks == 1, "cmvae_conv_gemm: statistics need a single column block");
+    if (g.rows_total == 0) return 0;
+    dim3 grid(gemm_grid(g.rows_total, n_col_blocks), n_col_blocks);
+    hipStream_t st = (hipStream_t)stream;
+    switch (act) {
+        case 0: hipLaunchKernelGGL(conv_gemm_kernel<0>, grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part); break;
+        case 1: hipLaunchKernelGGL(conv_gemm_kernel<1>, grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part); break;
+        default: hipLaunchKernelGGL(conv_gemm_kernel<2>, grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part); break;
+    }
+    return check_launch("conv_gemm_kernel");
+}
+
+extern "C" size_t cmvae_conv_wgrad_workspace_bytes(int rows_total) {
+    const int nblk = gemm_grid(rows_total, 2);
+    return align_up((size_t)nblk * 4 * 4096 * sizeof(float)) + align_up((size_t)nblk * 64 * sizeof(float));
+}
+
+extern "C" int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, const float* a_scale,
+                                const float* a_shift, const float* G, int g_pitch, int g_col,
+                                const int64_t* tap_off_host, int64_t s_ci, int64_t s_co, float* dW, float* db,
+                                int accumulate_db, void* workspace, size_t workspace_bytes, void* stream) {
+    CMVAE_REQUIRE(geom && A && G && tap_off_host && dW && workspace, "cmvae_conv_wgrad: NULL argument");
+    CMVAE_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "cmvae_conv_wgrad: scale and shift go together");
+    ConvGeom g = to_geom(geom);
+    if (int e = check_geom(g)) return e;
+    CMVAE_REQUIRE(g_pitch >= 64 && g_col >= 0 && g_col + 64 <= g_pitch && g_pitch % 4 == 0 && g_col % 4 == 0,
+                  "cmvae_conv_wgrad: bad gradient pitch/column");
+    CMVAE_REQUIRE(workspace_bytes >= cmvae_conv_wgrad_workspace_bytes(g.rows_total), "cmvae_conv_wgrad: workspace too small");
+    if (g.rows_total == 0) return 0;
+    const int nblk = gemm_grid(g.rows_total, 2);
+    float* part = (float*)workspace;
+    float* db_part = (float*)((char*)workspace + align_up((size_t)nblk * 4 * 4096 * sizeof(float)));
+    hipStream_t st = (hipStream_t)stream;
+    for (int t0 = 0; t0 < g.ntaps; t0 += 4) {
+        const int nt = g.ntaps - t0 < 4 ? g.ntaps - t0 : 4;
+        float* dbp = (db && t0 == 0) ? db_part : nullptr;
+        switch (nt) {
+            case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(nblk), dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 2: hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3(nblk), dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3(nblk), dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            default: hipLaunchKernelGGL(conv_wgrad_kernel<4>, dim3(nblk), dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+        }
+        if (int e = check_launch("conv_wgrad_kernel")) return e;
+        WgradOut o{};
+        for (int t = 0; t < nt; ++t) o.tap_off[t] = tap_off_host[t0 + t];
+        o.s_ci = s_ci; o.s_co = s_co;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nt * 4096 + 255) / 256), dim3(256), 0, st, part, nblk, nt, o, dW,
+                           dbp, dbp ? db : nullptr, accumulate_db);
+        if (int e = check_launch("wgrad_reduce_kernel")) return e;
+    }
+    return 0;
+}

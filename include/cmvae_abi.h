@@ -129,6 +129,41 @@ int cmvae_reparam_logq_bwd(const float* logvar, const float* eps, const float* g
  * (GMVAE.h_a, omniglot/model.py:159-166).  A [64,64]; h [1]; grad [64,64] (may be NULL). */
 int cmvae_expm_trace(const float* A, float* h, float* grad, void* stream);
 
+/* ==== dense contractions: fp32-MFMA gather-GEMM ========================================
+ * Activations are row-major [pixels, C] (channels-last).  One geometry describes conv 3x3
+ * (omniglot/module.py:14-29), each sub-pixel phase of the stride-2 transposed convs
+ * (omniglot/module.py:50-62), their data gradients, and nn.Linear (omniglot/model.py:65-76,
+ * module.py:80-86,148):
+ *   out[outpix(r), nb*64 + 0:64] = act( sum_t T(A[src(r,t), a_col[t] : +64]) @ W_t + bias )
+ * r enumerates (image, y, x) over the per-image grid [Hg,Wg]; src(r,t) = (image, y*sy+dy[t],
+ * x*sx+dx[t]) in the [Hi,Wi] input image (zero outside); outpix(r) = (image, y*oys+oy0,
+ * x*oxs+ox0) in the [Ho,Wo] output image.  W_t is stored [out col][k] (k contiguous):
+ * W + nb*w_nblk_stride + t*w_tap_stride + col*w_pitch + k.  T = relu(a*a_scale[c]+a_shift[c])
+ * when a_scale != NULL (the previous BatchNorm+ReLU folded into the operand load).          */
+typedef struct cmvae_conv_geom {
+    int32_t rows_total, Hg, Wg, Hi, Wi, sy, sx, Ho, Wo, oys, oxs, oy0, ox0, ntaps;
+    int32_t a_pitch, o_pitch, w_pitch;
+    int64_t w_tap_stride, w_nblk_stride;
+    int32_t dy[16], dx[16], a_col[16];
+} cmvae_conv_geom;
+
+/* act: 0 none, 1 ReLU, 2 ELU.  stats_part (optional, n_col_blocks == 1): per-block partial
+ * column sums of the pre-activation output, [cmvae_conv_gemm_grid(rows,1)][128] = {sum[64],
+ * sum of squares[64]} — the BatchNorm statistics of the layer, reduced in a fixed order.      */
+int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks);
+int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, const float* Wt, const float* bias,
+                    const float* a_scale, const float* a_shift, int act, int n_col_blocks,
+                    float* out, float* stats_part, void* stream);
+
+/* Weight gradient of the same contraction: dW[tap_off_host[t] + ci*s_ci + co*s_co] =
+ * sum_r T(A[src(r,t)])[ci] * G[outpix(r), g_col + co];  db[co] (+)= sum_r G[outpix(r), g_col+co].
+ * tap_off_host is a HOST array of geom->ntaps offsets.                                        */
+size_t cmvae_conv_wgrad_workspace_bytes(int rows_total);
+int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, const float* a_scale, const float* a_shift,
+                     const float* G, int g_pitch, int g_col, const int64_t* tap_off_host,
+                     int64_t s_ci, int64_t s_co, float* dW, float* db, int accumulate_db,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,129 @@
+"""fp32-MFMA gather-GEMM kernels (conv 3x3, transposed-conv phases, data/weight gradients, Linear)
+against PyTorch CPU fp32 references of the same ops.  Tolerance 1e-5 relative (exact-fp32 fma chains
+only differ from the reference in summation order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def nhwc(x):       # [n,C,H,W] -> [n*H*W, C]
+    return x.permute(0, 2, 3, 1).contiguous().view(-1, x.shape[1])
+
+
+def from_nhwc(m, n, H, W):
+    return m.view(n, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize('n,H,W', [(3, 7, 7), (5, 14, 14), (2, 4, 4), (130, 2, 2)])
+def test_conv3x3_fwd_dgrad_wgrad(device, n, H, W):
+    from cmvae_amd import conv
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 64, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(64, generator=g).requires_grad_(True)
+    y = F.conv2d(x, w, b, 1, 1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(device)
+    wt = w.detach().permute(2, 3, 0, 1).contiguous().to(device)            # [9][co][ci]
+    out = torch.empty(n * H * W, 64, device=device)
+    geom = conv.geom_conv3x3(n, H, W)
+    part = conv.conv_gemm(geom, xd, wt, out, bias=b.detach().to(device), stats=True)
+    assert rel_err(from_nhwc(out.cpu(), n, H, W), y) < TOL
+    st = part.sum(0).cpu()
+    assert rel_err(st[:64], y.detach().sum((0, 2, 3))) < 1e-4
+    assert rel_err(st[64:], (y.detach() ** 2).sum((0, 2, 3))) < 1e-4
+    # data gradient
+    gyd = nhwc(gy).to(device)
+    wtd = w.detach().permute(2, 3, 1, 0).contiguous().to(device)           # [9][ci][co]
+    dx = torch.empty(n * H * W, 64, device=device)
+    conv.conv_gemm(conv.geom_conv3x3(n, H, W, transpose=True), gyd, wtd, dx)
+    assert rel_err(from_nhwc(dx.cpu(), n, H, W), x.grad) < TOL
+    # weight gradient: dW[co][ci][ky][kx]
+    dW = torch.zeros(64, 64, 3, 3, device=device)
+    db = torch.zeros(64, device=device)
+    conv.conv_wgrad(geom, xd, gyd, dW, [t for t in range(9)], s_ci=9, s_co=64 * 9, db=db)
+    assert rel_err(dW, w.grad) < TOL
+    assert rel_err(db, b.grad) < TOL
+
+
+@pytest.mark.parametrize('n,Hi,k', [(6, 2, 4), (5, 4, 3), (3, 7, 4), (70, 7, 4)])
+def test_convT_phases_with_bn_fold(device, n, Hi, k):
+    """Transposed conv over relu(bn(x)) folded into the operand load; dgrad; wgrad."""
+    from cmvae_amd import conv
+    g = torch.Generator().manual_seed(k + Hi)
+    x = torch.randn(n, 64, Hi, Hi, generator=g)
+    sc = torch.rand(64, generator=g) + 0.5
+    sh = torch.randn(64, generator=g) * 0.3
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    w = (torch.randn(64, 64, k, k, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(64, generator=g).requires_grad_(True)
+    y = F.conv_transpose2d(a, w, b, 2, 1)
+    Ho = y.shape[-1]
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x).to(device)
+    scd, shd, bd = sc.to(device), sh.to(device), b.detach().to(device)
+    wprep = w.detach().permute(2, 3, 1, 0).contiguous().view(k * k, 64, 64).to(device)   # [tap][co][ci]
+    out = torch.full((n * Ho * Ho, 64), float('nan'), device=device)
+    gyd = nhwc(gy).to(device)
+    dW = torch.zeros(64, 64, k, k, device=device)
+    db = torch.zeros(64, device=device)
+    ssum = torch.zeros(128)
+    first = True
+    for py in (0, 1):
+        for px in (0, 1):
+            geom, tap_idx = conv.geom_convT_phase(n, Hi, Hi, k, py, px)
+            wp = wprep[tap_idx].contiguous()
+            part = conv.conv_gemm(geom, xd, wp, out, bias=bd, a_scale=scd, a_shift=shd, stats=True)
+            ssum += part.sum(0).cpu()
+            conv.conv_wgrad(geom, xd, gyd, dW, tap_idx, s_ci=64 * k * k, s_co=k * k, db=db, accumulate_db=not first,
+                            a_scale=scd, a_shift=shd)
+            first = False
+    assert rel_err(from_nhwc(out.cpu(), n, Ho, Ho), y) < TOL
+    assert rel_err(ssum[:64], y.detach().sum((0, 2, 3))) < 1e-4
+    assert rel_err(dW, w.grad) < TOL
+    assert rel_err(db, b.grad) < TOL
+    # data gradient wrt a (the post-activation input)
+    wtd = w.detach().permute(2, 3, 0, 1).contiguous().to(device)      # [tap][ci][co]
+    da = torch.empty(n * Hi * Hi, 64, device=device)
+    conv.conv_gemm(conv.geom_convT_dgrad(n, Hi, Hi, k), gyd, wtd, da)
+    assert rel_err(from_nhwc(da.cpu(), n, Hi, Hi), a.grad) < TOL
+
+
+@pytest.mark.parametrize('rows,K,N,act', [(300, 128, 256, 2), (1000, 256, 256, 1), (77, 256, 128, 0),
+                                          (513, 64, 2048, 0)])
+def test_linear_fwd_dgrad_wgrad(device, rows, K, N, act):
+    from cmvae_amd import conv
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, K, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(N, generator=g).requires_grad_(True)
+    pre = F.linear(x, w, b)
+    y = [pre, torch.relu(pre), F.elu(pre)][act]
+    gp = torch.randn(pre.shape, generator=g)
+    pre.backward(gp)
+    xd, wd, bd = x.detach().to(device), w.detach().to(device), b.detach().to(device)
+    out = torch.empty(rows, N, device=device)
+    conv.conv_gemm(conv.geom_linear(rows, K, N), xd, wd, out, bias=bd, act=act, n_col_blocks=N // 64)
+    assert rel_err(out, y) < TOL
+    # dx = gp @ W : a Linear with weight W^T [K,N]
+    gpd = gp.to(device)
+    dx = torch.empty(rows, K, device=device)
+    if N // 64 <= 16:
+        conv.conv_gemm(conv.geom_linear(rows, N, K), gpd, wd.t().contiguous(), dx, n_col_blocks=K // 64)
+        assert rel_err(dx, x.grad) < TOL
+    # dW[n][k], db[n]
+    dW = torch.zeros(N, K, device=device)
+    db = torch.zeros(N, device=device)
+    geom = conv.geom_linear(rows, K, N)
+    for nb in range(N // 64):
+        conv.conv_wgrad(geom, xd, gpd, dW, [nb * 64 * K + 64 * t for t in range(K // 64)], s_ci=1, s_co=K,
+                        db=db[nb * 64:], g_pitch=N, g_col=nb * 64)
+    assert rel_err(dW, w.grad) < TOL
+    assert rel_err(db, b.grad) < TOL
