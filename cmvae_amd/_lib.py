@@ -58,6 +58,22 @@ SIGNATURES = {
     'cmvae_reparam_logq_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p]),
     'cmvae_expm_trace': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_colsum_reduce': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'cmvae_bn_finalize': (c_int, [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_rowpass_grid': (c_int, [c_int64]),
+    'cmvae_bn_relu_bwd_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                         c_void_p, c_void_p]),
+    'cmvae_bn_bwd_finalize': (c_int, [c_void_p, c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
+    'cmvae_bn_relu_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    'cmvae_dec_out_grid': (c_int, [c_int]),
+    'cmvae_dec_out_bwd_partial_len': (c_int, []),
+    'cmvae_dec_out_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p]),
+    'cmvae_dec_out_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     'cmvae_conv_gemm_grid': (c_int, [c_int, c_int]),
     'cmvae_conv_gemm': (c_int, [_PG, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p]),

@@ -86,7 +86,9 @@ def gemm_grid(rows, ncb=1):
 def conv_gemm(g, A, Wt, out, bias=None, a_scale=None, a_shift=None, act=0, n_col_blocks=1, stats=False):
     """Launch the forward gather-GEMM.  Returns per-block partial statistics [grid,128] if asked."""
     part = None
-    if stats:
+    if isinstance(stats, torch.Tensor):
+        part = stats                     # caller-provided [gemm_grid(rows,1),128] slice
+    elif stats:
         part = torch.empty(gemm_grid(g.rows_total, 1), 128, device=A.device, dtype=torch.float32)
     check(lib.cmvae_conv_gemm(ctypes.byref(g), _p(A), _p(Wt), _p(bias), _p(a_scale), _p(a_shift), act, n_col_blocks,
                               _p(out), _p(part), _stream()), 'cmvae_conv_gemm')

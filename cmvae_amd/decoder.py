@@ -1,0 +1,203 @@
+"""OmniglotDecoder + Bernoulli likelihood as one autograd node on the HIP kernels
+(omniglot/module.py:43-71, omniglot/model.py:458-466).
+
+Forward:  H_rec [n,256] (channels-last: column (i*2+j)*64 + c) -> three ConvTranspose2d layers as
+sub-pixel-phase gather-GEMMs (BatchNorm statistics from the GEMM epilogue, BatchNorm+ReLU folded into
+the next layer's operand load) -> fused ConvTranspose2d(64,1)+Sigmoid+BCE.
+Backward: fused last layer (+ ReLU mask + BN-backward sums), then per layer BN-backward apply, the
+weight-gradient GEMMs, the data-gradient GEMM and the BN-backward reduction of the layer below.
+Pre-BatchNorm activations y1..y3 are the only tensors kept for the backward pass.
+"""
+import ctypes
+
+import torch
+
+from . import conv
+from . import dist as _dist
+from ._lib import lib, check
+
+_p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+_LAYERS = ((4, 2), (3, 4), (4, 7))          # (kernel, input size) of the three 64->64 transposed convs
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def colsum(part):
+    out = torch.empty(part.shape[1], device=part.device)
+    check(lib.cmvae_colsum_reduce(_p(part), part.shape[0], part.shape[1], _p(out), _stream()), 'cmvae_colsum_reduce')
+    return out
+
+
+def bn_finalize(sums, count, bn, training_update=True):
+    dev = sums.device
+    scale, shift, mean, invstd = (torch.empty(64, device=dev) for _ in range(4))
+    upd = training_update and bn.track_running_stats
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    check(lib.cmvae_bn_finalize(_p(sums), float(count), _p(bn.weight.detach()), _p(bn.bias.detach()), bn.eps, mom,
+                                _p(bn.running_mean) if upd else None, _p(bn.running_var) if upd else None,
+                                _p(scale), _p(shift), _p(mean), _p(invstd), _stream()), 'cmvae_bn_finalize')
+    if upd:
+        bn.num_batches_tracked += 1
+    return scale, shift, mean, invstd
+
+
+def bn_eval_fold(bn):
+    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    return scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+
+
+def _global_sums(sums):
+    if _dist.world_size() > 1:
+        g = sums.clone()
+        torch.distributed.all_reduce(g)
+        return g
+    return sums
+
+
+def bn_bwd_finalize(sums_local, count):
+    dev = sums_local.device
+    c1, c2, dgamma, dbeta = (torch.empty(64, device=dev) for _ in range(4))
+    sums_global = _global_sums(sums_local)
+    check(lib.cmvae_bn_bwd_finalize(_p(sums_local), _p(sums_global), float(count * _dist.world_size()), _p(c1), _p(c2),
+                                    _p(dgamma), _p(dbeta), _stream()), 'cmvae_bn_bwd_finalize')
+    return c1, c2, dgamma, dbeta
+
+
+def bn_relu_bwd_sums(d_a, y, fold, masked):
+    rows = y.shape[0]
+    part = torch.empty(lib.cmvae_rowpass_grid(rows), 128, device=y.device)
+    check(lib.cmvae_bn_relu_bwd_reduce(_p(d_a), _p(y), _p(fold[0]), _p(fold[1]), _p(fold[2]), _p(fold[3]), rows,
+                                       int(masked), _p(part), _stream()), 'cmvae_bn_relu_bwd_reduce')
+    return colsum(part)
+
+
+def bn_relu_bwd_apply(d_a, y, fold, c1, c2, masked, out):
+    check(lib.cmvae_bn_relu_bwd_apply(_p(d_a), _p(y), _p(fold[0]), _p(fold[1]), _p(fold[2]), _p(fold[3]), _p(c1),
+                                      _p(c2), y.shape[0], int(masked), _p(out), _stream()), 'cmvae_bn_relu_bwd_apply')
+    return out
+
+
+def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
+    """x [n*Hi*Hi,64] (pre-fold) -> y [n*Ho*Ho,64]; returns (y, column sums {sum,sumsq} or None)."""
+    Ho = conv.convT_out(Hi, k)
+    y = torch.empty(n * Ho * Ho, 64, device=x.device)
+    wprep = weight.detach().permute(2, 3, 1, 0).reshape(k * k, 64, 64)       # [tap][co][ci]
+    phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px) for py in (0, 1) for px in (0, 1)]
+    part = None
+    if want_stats:
+        grids = [conv.gemm_grid(g.rows_total, 1) for g, _ in phases]
+        part = torch.empty(sum(grids), 128, device=x.device)
+    off = 0
+    sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
+    for i, (g, tap_idx) in enumerate(phases):
+        wp = wprep[tap_idx].contiguous()
+        st = part[off:off + grids[i]] if want_stats else False
+        conv.conv_gemm(g, x, wp, y, bias=bias.detach(), a_scale=sc, a_shift=sh, stats=st)
+        if want_stats:
+            off += grids[i]
+    return y, (colsum(part) if want_stats else None)
+
+
+class _DecoderBCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h_rec, target, M, training, bns, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, w4, b4):
+        n = h_rec.shape[0]
+        ws, bs = (w1, w2, w3), (b1, b2, b3)
+        acts, folds = [h_rec.detach().reshape(n * 4, 64)], [None]
+        world = _dist.world_size()
+        for li, (k, Hi) in enumerate(_LAYERS):
+            y, sums = convT_forward(acts[-1], n, Hi, k, ws[li], bs[li], folds[-1], want_stats=training)
+            if training:
+                count = y.shape[0] * world
+                fold = bn_finalize(_global_sums(sums), count, bns[li])
+            else:
+                fold = bn_eval_fold(bns[li])
+            acts.append(y)
+            folds.append(fold)
+        p = torch.empty(n, 784, device=h_rec.device)
+        loss_part = torch.empty(n, device=h_rec.device)
+        tgt = target.detach().reshape(-1, 784)
+        if tgt.shape[0] * M != n:
+            raise RuntimeError('cmvae_amd: decoder got %d images for %d targets x M=%d' % (n, tgt.shape[0], M))
+        w4f = w4.detach().reshape(64, 16).contiguous()
+        check(lib.cmvae_dec_out_fwd(_p(acts[3]), _p(folds[3][0]), _p(folds[3][1]), _p(w4f), _p(b4.detach()), _p(tgt), M,
+                                    n, _p(p), _p(loss_part), _stream()), 'cmvae_dec_out_fwd')
+        loss = loss_part.sum()
+        ctx.training = training
+        ctx.M = M
+        ctx.n = n
+        ctx.acts, ctx.folds = acts, folds
+        ctx.save_for_backward(p, tgt, w1, w2, w3, w4f)
+        ctx.mark_non_differentiable(p)
+        ctx.set_materialize_grads(False)
+        return p, loss
+
+    @staticmethod
+    def backward(ctx, _gp, g_loss):
+        if not ctx.training:
+            raise RuntimeError('cmvae_amd: decoder backward is only defined in training mode (batch statistics)')
+        p, tgt, w1, w2, w3, w4f = ctx.saved_tensors
+        ws = (w1, w2, w3)
+        n, M, acts, folds = ctx.n, ctx.M, ctx.acts, ctx.folds
+        dev = p.device
+        L = lib.cmvae_dec_out_bwd_partial_len()
+        part = torch.empty(lib.cmvae_dec_out_grid(n), L, device=dev)
+        d = torch.empty(n * 196, 64, device=dev)
+        g_loss = g_loss.contiguous().float()
+        check(lib.cmvae_dec_out_bwd(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n, _p(g_loss),
+                                    1.0, _p(d), _p(part), _stream()), 'cmvae_dec_out_bwd')
+        tot = colsum(part)
+        dw4 = tot[:1024].reshape(64, 1, 4, 4)
+        db4 = tot[1152:1153]
+        sums = tot[1024:1152]
+        grads_w, grads_b, grads_g, grads_be = [None] * 3, [None] * 3, [None] * 3, [None] * 3
+        masked = True
+        for li in (2, 1, 0):
+            k, Hi = _LAYERS[li]
+            y, fold, x_in, fold_in = acts[li + 1], folds[li + 1], acts[li], folds[li]
+            c1, c2, dgamma, dbeta = bn_bwd_finalize(sums, y.shape[0])
+            dy = bn_relu_bwd_apply(d, y, fold, c1, c2, masked, out=d)             # in place
+            grads_g[li], grads_be[li] = dgamma, dbeta
+            dW = torch.empty_like(ws[li])
+            db = torch.empty(64, device=dev)
+            sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
+            first = True
+            for py in (0, 1):
+                for px in (0, 1):
+                    g, tap_idx = conv.geom_convT_phase(n, Hi, Hi, k, py, px)
+                    conv.conv_wgrad(g, x_in, dy, dW, tap_idx, s_ci=64 * k * k, s_co=k * k, db=db,
+                                    accumulate_db=not first, a_scale=sc, a_shift=sh)
+                    first = False
+            grads_w[li], grads_b[li] = dW, db
+            wtd = ws[li].detach().permute(2, 3, 0, 1).reshape(k * k, 64, 64).contiguous()   # [tap][ci][co]
+            d_in = torch.empty(n * Hi * Hi, 64, device=dev)
+            conv.conv_gemm(conv.geom_convT_dgrad(n, Hi, Hi, k), dy, wtd, d_in)
+            d = d_in
+            if li > 0:
+                sums = bn_relu_bwd_sums(d, x_in, fold_in, masked=False)
+                masked = False
+        d_h = d.reshape(n, 256)
+        return (d_h, None, None, None, None,
+                grads_w[0], grads_b[0], grads_g[0], grads_be[0],
+                grads_w[1], grads_b[1], grads_g[1], grads_be[1],
+                grads_w[2], grads_b[2], grads_g[2], grads_be[2], dw4, db4)
+
+
+# proj output column (pix*64 + c)  <-  reference column (c*4 + pix): channels-last view of [64,2,2]
+def nhwc_perm(device):
+    j = torch.arange(256, device=device)
+    return (j % 64) * 4 + j // 64
+
+
+def decoder_bce(decoder, h_rec_nhwc, target, M):
+    """Returns (X_rec probabilities [n,784], BCE sum).  h_rec_nhwc: [n,256] in channels-last order."""
+    seq = decoder.decoder
+    convs = (seq[0], seq[3], seq[6], seq[9])
+    bns = (seq[1], seq[4], seq[7])
+    args = []
+    for i in range(3):
+        args += [convs[i].weight, convs[i].bias, bns[i].weight, bns[i].bias]
+    args += [convs[3].weight, convs[3].bias]
+    return _DecoderBCE.apply(h_rec_nhwc.contiguous(), target, M, decoder.training, bns, *args)

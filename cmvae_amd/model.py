@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .module import OmniglotEncoder, OmniglotDecoder, SAB, CausalEncoder
+from .decoder import decoder_bce, nhwc_perm
 
 _LOG_NORM = -0.5 * np.log(2 * np.pi)
 
@@ -170,10 +171,14 @@ class OmniglotGMVAE(_GMVAEBase):
         q_z = q_z4.view(B, S * M, D)
         q_eps = self.causal(q_z - q_z.mean(1, keepdim=True))
         A = self.causal.get_w()
-        H_rec = self.proj(torch.cat([q_z, q_eps], -1).view(-1, 2 * D))
-        X_rec = self.decoder(H_rec).view(B, S, M, *self.input_shape)
-        target = X[:, :, None].expand(-1, -1, M, -1, -1, -1)
-        rec_loss = F.binary_cross_entropy(X_rec, target, reduction='sum') / (B * S * M)
+        # proj: the last Linear's rows are permuted so H_rec comes out channels-last ([2,2,64] per image)
+        h = self.proj[:4](torch.cat([q_z, q_eps], -1).view(-1, 2 * D))
+        perm = nhwc_perm(h.device)
+        H_rec = F.elu(F.linear(h, self.proj[4].weight[perm], self.proj[4].bias[perm]))
+        # decoder + Bernoulli likelihood: one fused HIP pipeline (cmvae_amd/decoder.py)
+        p_rec, bce_sum = decoder_bce(self.decoder, H_rec, X.reshape(B * S, -1), M)
+        X_rec = p_rec.view(B, S, M, *self.input_shape)
+        rec_loss = bce_sum / (B * S * M)
         kl_loss, h_augment, h = self._kl_and_h(q_z, log_q_z, q_eps, A, h_lambda, h_c, a_lambda, init_idx, extras)
         if extras is not None:
             extras.update(q_z_mean=q_mean, q_z_logvar=q_logvar)

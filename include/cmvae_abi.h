@@ -164,6 +164,46 @@ int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, const float* a
                      int64_t s_ci, int64_t s_co, float* dW, float* db, int accumulate_db,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ==== BatchNorm (training statistics over the whole meta-batch) on channels-last [rows,64]
+ * nn.BatchNorm2d after every conv (omniglot/module.py:15,20,25,30,51,55,59).  The conv GEMM
+ * emits per-block partial sums; these finish the job.                                        */
+int cmvae_colsum_reduce(const float* part, int nblk, int L, float* out, void* stream);   /* out[L] = sum_b part[b][L] */
+/* sums = {sum x[64], sum x^2[64]} over `count` values per channel (all-reduce them first when the
+ * episodes are sharded).  Writes scale = gamma*invstd, shift = beta - mean*scale, mean, invstd and
+ * updates running_mean / running_var (momentum, unbiased variance) when they are not NULL.     */
+int cmvae_bn_finalize(const float* sums, double count, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var,
+                      float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* backward of relu(bn(y)): dybn = d_a*(bn(y)>0) (masked != 0: d_a is already masked);
+ * part [cmvae_rowpass_grid(rows)][128] = {sum dybn, sum dybn*xhat}; then
+ * dy = scale*(dybn - c1 - xhat*c2) with c1, c2 from cmvae_bn_bwd_finalize.                     */
+int cmvae_rowpass_grid(int64_t rows);
+int cmvae_bn_relu_bwd_reduce(const float* d_a, const float* y, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, int64_t rows, int masked,
+                             float* part, void* stream);
+int cmvae_bn_bwd_finalize(const float* sums_local, const float* sums_global, double count,
+                          float* c1, float* c2, float* dgamma, float* dbeta, void* stream);
+int cmvae_bn_relu_bwd_apply(const float* d_a, const float* y, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, const float* c1, const float* c2,
+                            int64_t rows, int masked, float* dy, void* stream);
+
+/* ==== last decoder layer fused with the Bernoulli likelihood
+ * relu(bn3(y3)) -> ConvTranspose2d(64,1,4,2,1) -> Sigmoid -> BCELoss(sum)
+ * (omniglot/module.py:62-63, omniglot/model.py:83,463-466).  y3 [nimg,14,14,64]; w4 [64,16];
+ * target [nimg/M, 784] (the image each MC sample reconstructs); p_out [nimg,784];
+ * loss_part [nimg] (per-image BCE sums, log clamped at -100 as nn.BCELoss does).
+ * bwd: dybn [nimg,14,14,64] = masked gradient w.r.t. bn3 output; part
+ * [cmvae_dec_out_grid(nimg)][cmvae_dec_out_bwd_partial_len()] = {dW4[64][16], sum dybn[64],
+ * sum dybn*xhat[64], db4}.  Upstream gradient of the BCE sum = gmul * g_dev[0] (g_dev: device
+ * scalar or NULL for 1).                                                                       */
+int cmvae_dec_out_grid(int nimg);
+int cmvae_dec_out_bwd_partial_len(void);
+int cmvae_dec_out_fwd(const float* y3, const float* scale, const float* shift, const float* w4, const float* b4,
+                      const float* target, int M, int nimg, float* p_out, float* loss_part, void* stream);
+int cmvae_dec_out_bwd(const float* y3, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, const float* w4, const float* p, const float* target, int M, int nimg,
+                      const float* g_dev, float gmul, float* dybn, float* part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
