@@ -1,0 +1,258 @@
+// OmniglotEncoder pieces that are not 64->64 GEMMs (omniglot/module.py:12-33), channels-last:
+//   * Conv2d(1,64,3,1,1) on 28x28 (K = 9: VALU, HBM-bound on the 64-channel output) + its weight grad
+//   * MaxPool2d(2, ceil_mode=True) fused with the preceding BatchNorm + ReLU, forward and backward
+//     (the backward also emits the BatchNorm-backward sums).
+#include "common.h"
+
+namespace cmvae {
+
+constexpr int EC = 64;
+
+// ------------------------------------------------------------------ conv 1->64, 3x3, pad 1
+// x [n,H,W]; w [64][9]; y [n*H*W, 64]; part[blk][128] = {sum y, sum y^2} (optional)
+__global__ __launch_bounds__(256) void enc_conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, int H, int W, long rows,
+                                                            float* __restrict__ y, float* __restrict__ part) {
+    __shared__ float red[16 * 128];
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
+    float wr[4][9], br[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        br[c] = b[4 * q + c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(4 * q + c) * 9 + t];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int hw = H * W;
+    for (long r = (long)blockIdx.x * 16 + rb; r < rows; r += (long)gridDim.x * 16) {
+        const long n = r / hw;
+        const int rem = (int)(r - n * hw);
+        const int py = rem / W, px = rem - py * W;
+        const float* xi = x + n * hw;
+        float acc[4] = {br[0], br[1], br[2], br[3]};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = py + ky - 1;
+            if (sy < 0 || sy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = px + kx - 1;
+                if (sx < 0 || sx >= W) continue;
+                const float xv = xi[sy * W + sx];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, wr[c][ky * 3 + kx], acc[c]);
+            }
+        }
+        reinterpret_cast<float4*>(y + r * EC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
+    }
+    if (part) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { red[rb * 128 + 4 * q + c] = s1[c]; red[rb * 128 + 64 + 4 * q + c] = s2[c]; }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * 128 + threadIdx.x];
+            part[(long)blockIdx.x * 128 + threadIdx.x] = s;
+        }
+    }
+}
+
+// part[blk][640] = { dW[64][9], db[64] },  dW[c][t] = sum_r dy[r][c] * x[src(r,t)]
+__global__ __launch_bounds__(256) void enc_conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              int H, int W, long rows, float* __restrict__ part) {
+    __shared__ float red[16 * 640];
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
+    float acc[4][9], db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    const int hw = H * W;
+    for (long r = (long)blockIdx.x * 16 + rb; r < rows; r += (long)gridDim.x * 16) {
+        const long n = r / hw;
+        const int rem = (int)(r - n * hw);
+        const int py = rem / W, px = rem - py * W;
+        const float* xi = x + n * hw;
+        const float4 g4 = reinterpret_cast<const float4*>(dy + r * EC)[q];
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) db[c] += g[c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = py + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = px + kx - 1;
+                const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                const float xv = ok ? xi[sy * W + sx] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c][ky * 3 + kx] = fmaf(g[c], xv, acc[c][ky * 3 + kx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[rb * 640 + (4 * q + c) * 9 + t] = acc[c][t];
+        red[rb * 640 + 576 + 4 * q + c] = db[c];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 640; e += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r * 640 + e];
+        part[(long)blockIdx.x * 640 + e] = s;
+    }
+}
+
+// ------------------------------------------------------------------ relu(bn(y)) -> maxpool 2x2 (ceil)
+__device__ __forceinline__ float4 fold4(const float4 v, const float4 sc, const float4 sh) {
+    return make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f),
+                       fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+}
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int H, int W, int Ho, int Wo,
+                                                       long orows, float* __restrict__ out) {
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    const int ohw = Ho * Wo;
+    for (long r = (long)blockIdx.x * 16 + rb; r < orows; r += (long)gridDim.x * 16) {
+        const long n = r / ohw;
+        const int rem = (int)(r - n * ohw);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int sy = 2 * oy + dy;
+            if (sy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int sx = 2 * ox + dx;
+                if (sx >= W) continue;
+                const float4 v = fold4(reinterpret_cast<const float4*>(y + ((n * H + sy) * W + sx) * EC)[q], sc, sh);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        reinterpret_cast<float4*>(out + r * EC)[q] = m;
+    }
+}
+
+// d_pool [n,Ho,Wo,64] -> dybn [n,H,W,64] (gradient w.r.t. the BatchNorm output, ReLU mask applied; the
+// first maximum of a window receives it, as PyTorch's max_pool2d does) and
+// part[blk][128] = {sum dybn, sum dybn*xhat}
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ d_pool, const float* __restrict__ y,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, int H, int W, int Ho, int Wo,
+                                                       long orows, float* __restrict__ dybn,
+                                                       float* __restrict__ part) {
+    __shared__ float red[16 * 128];
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    const float4 mu4 = reinterpret_cast<const float4*>(mean)[q], is4 = reinterpret_cast<const float4*>(invstd)[q];
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ohw = Ho * Wo;
+    for (long r = (long)blockIdx.x * 16 + rb; r < orows; r += (long)gridDim.x * 16) {
+        const long n = r / ohw;
+        const int rem = (int)(r - n * ohw);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const float4 g4 = reinterpret_cast<const float4*>(d_pool + r * EC)[q];
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float raw[4][4], val[4][4];      // [window slot][channel]
+        bool in[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sy = 2 * oy + (s >> 1), sx = 2 * ox + (s & 1);
+            in[s] = sy < H && sx < W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in[s]) v = reinterpret_cast<const float4*>(y + ((n * H + sy) * W + sx) * EC)[q];
+            const float4 f = fold4(v, sc, sh);
+            raw[s][0] = v.x; raw[s][1] = v.y; raw[s][2] = v.z; raw[s][3] = v.w;
+            val[s][0] = f.x; val[s][1] = f.y; val[s][2] = f.z; val[s][3] = f.w;
+        }
+        float o[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int best = 0;
+            float bv = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (in[s] && val[s][c] > bv) { bv = val[s][c]; best = s; }
+            const float gg = bv > 0.f ? g[c] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o[s][c] = (s == best) ? gg : 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (s == best) { s1[c] += gg; s2[c] = fmaf(gg, (raw[s][c] - mu[c]) * is[c], s2[c]); }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!in[s]) continue;
+            const int sy = 2 * oy + (s >> 1), sx = 2 * ox + (s & 1);
+            reinterpret_cast<float4*>(dybn + ((n * H + sy) * W + sx) * EC)[q] =
+                make_float4(o[s][0], o[s][1], o[s][2], o[s][3]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { red[rb * 128 + 4 * q + c] = s1[c]; red[rb * 128 + 64 + 4 * q + c] = s2[c]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r * 128 + threadIdx.x];
+        part[(long)blockIdx.x * 128 + threadIdx.x] = s;
+    }
+}
+
+static int rp_grid(long rows) {
+    long g = (rows + 15) / 16;
+    if (g > 2048) g = 2048;
+    return g < 1 ? 1 : (int)g;
+}
+
+}  // namespace cmvae
+
+using namespace cmvae;
+
+extern "C" int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* b, int n, int H, int W, float* y,
+                                   float* stats_part, void* stream) {
+    CMVAE_REQUIRE(x && w && b && y && n >= 1 && H >= 1 && W >= 1, "cmvae_enc_conv1_fwd: bad arguments");
+    const long rows = (long)n * H * W;
+    hipLaunchKernelGGL(enc_conv1_fwd_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, w, b, H, W, rows,
+                       y, stats_part);
+    return check_launch("enc_conv1_fwd_kernel");
+}
+
+extern "C" int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, float* part, void* stream) {
+    CMVAE_REQUIRE(x && dy && part && n >= 1 && H >= 1 && W >= 1, "cmvae_enc_conv1_wgrad: bad arguments");
+    const long rows = (long)n * H * W;
+    hipLaunchKernelGGL(enc_conv1_wgrad_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, dy, H, W, rows,
+                       part);
+    return check_launch("enc_conv1_wgrad_kernel");
+}
+
+extern "C" int cmvae_pool_fwd(const float* y, const float* scale, const float* shift, int n, int H, int W, float* out,
+                              void* stream) {
+    CMVAE_REQUIRE(y && scale && shift && out && n >= 1 && H >= 1 && W >= 1, "cmvae_pool_fwd: bad arguments");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long orows = (long)n * Ho * Wo;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(rp_grid(orows)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, H, W,
+                       Ho, Wo, orows, out);
+    return check_launch("pool_fwd_kernel");
+}
+
+extern "C" int cmvae_pool_bwd(const float* d_pool, const float* y, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, int n, int H, int W, float* dybn, float* part,
+                              void* stream) {
+    CMVAE_REQUIRE(d_pool && y && scale && shift && mean && invstd && dybn && part && n >= 1, "cmvae_pool_bwd: bad arguments");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long orows = (long)n * Ho * Wo;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(rp_grid(orows)), dim3(256), 0, (hipStream_t)stream, d_pool, y, scale, shift,
+                       mean, invstd, H, W, Ho, Wo, orows, dybn, part);
+    return check_launch("pool_bwd_kernel");
+}

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from . import ops
 from .module import OmniglotEncoder, OmniglotDecoder, SAB, CausalEncoder
 from .decoder import decoder_bce, nhwc_perm
+from .encoder import encode_images
 
 _LOG_NORM = -0.5 * np.log(2 * np.pi)
 
@@ -158,7 +159,10 @@ class OmniglotGMVAE(_GMVAEBase):
 
     def _encode(self, X):
         B, S = X.shape[:2]
-        H = self.encoder(X.reshape(-1, *self.input_shape)).view(B, S, self.last_hidden_size)
+        # HIP encoder; its output is channels-last, gather the columns back to the reference's c*4+pix order
+        H = encode_images(self.encoder, X.reshape(B * S, -1))
+        j = torch.arange(self.last_hidden_size, device=H.device)
+        H = H[:, (j % 4) * self.hidden_size + j // 4].view(B, S, self.last_hidden_size)
         return self.q_z_given_H(H).split(self.latent_size, dim=-1)
 
     def forward(self, X, h_lambda, h_c, a_lambda, eps=None, init_idx=None, extras=None):

@@ -204,6 +204,21 @@ int cmvae_dec_out_bwd(const float* y3, const float* scale, const float* shift, c
                       const float* invstd, const float* w4, const float* p, const float* target, int M, int nimg,
                       const float* g_dev, float gmul, float* dybn, float* part, void* stream);
 
+/* ==== OmniglotEncoder pieces that are not 64->64 GEMMs (omniglot/module.py:12-33)
+ * Conv2d(1,64,3,1,1): x [n,H,W] -> y [n*H*W,64]; w [64,9]; stats_part (optional)
+ * [cmvae_rowpass_grid(n*H*W)][128].  wgrad: part [cmvae_rowpass_grid(n*H*W)][640] = {dW[64][9], db[64]}.
+ * pool: relu(bn(y)) then MaxPool2d(2, ceil_mode=True): y [n,H,W,64] -> out [n,ceil(H/2),ceil(W/2),64];
+ * bwd: d_pool -> dybn [n,H,W,64] (first maximum takes the gradient, ReLU mask applied) and
+ * part [cmvae_rowpass_grid(n*Ho*Wo)][128] = {sum dybn, sum dybn*xhat}.                            */
+int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* b, int n, int H, int W,
+                        float* y, float* stats_part, void* stream);
+int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, float* part, void* stream);
+int cmvae_pool_fwd(const float* y, const float* scale, const float* shift, int n, int H, int W,
+                   float* out, void* stream);
+int cmvae_pool_bwd(const float* d_pool, const float* y, const float* scale, const float* shift,
+                   const float* mean, const float* invstd, int n, int H, int W,
+                   float* dybn, float* part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
