@@ -71,8 +71,9 @@ __device__ __forceinline__ float4 load_a(const ConvGeom& g, const float* __restr
                                          int q, bool* ok) {
     const int sy = ri.ys + g.dy[t], sx = ri.xs + g.dx[t];
     *ok = ri.valid && sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
-    if (!*ok) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const long pix = (long)ri.base + sy * g.Wi + sx;
+    // branch-free: an outside tap loads pixel 0 (always mapped) and is zeroed by transform_a; a branch
+    // around each load would make hipcc wait for every load separately
+    const long pix = *ok ? (long)ri.base + sy * g.Wi + sx : 0;
     return *reinterpret_cast<const float4*>(A + pix * g.a_pitch + g.a_col[t] + 4 * q);
 }
 
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
             const int r = tile * BM + rb + 16 * e;
             ri[e] = row_info(g, r);
             const int op = out_pixel(g, r);
-            rg[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (op >= 0) rg[e] = *reinterpret_cast<const float4*>(G + (long)op * g_pitch + g_col + 4 * q);
+            rg[e] = *reinterpret_cast<const float4*>(G + (long)(op >= 0 ? op : 0) * g_pitch + g_col + 4 * q);
+            if (op < 0) rg[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             dbs.x += rg[e].x; dbs.y += rg[e].y; dbs.z += rg[e].z; dbs.w += rg[e].w;
             ra[e] = load_a(g, A, ri[e], tap0, q, &ok[e]);
         }
