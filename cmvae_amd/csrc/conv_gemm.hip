@@ -32,12 +32,12 @@ struct ConvGeom {
     int w_pitch;              // floats between consecutive output columns of W_t ([col][k] layout)
     long w_tap_stride;        // floats between taps
     long w_nblk_stride;       // floats between 64-column output blocks (blockIdx.y)
-    signed char dy[16], dx[16];
+    int dy[16], dx[16];       // dword arrays: indexed by the (uniform) tap counter they stay in SGPRs
     int a_col[16];
 };
 
 struct RowInfo {
-    int base;                 // image * Hi*Wi
+    int off;                  // element offset of source pixel (image, y*sy, x*sx): pixel * a_pitch
     int ys, xs;               // y*sy, x*sx
     bool valid;
 };
@@ -50,9 +50,9 @@ __device__ __forceinline__ RowInfo row_info(const ConvGeom& g, int r) {
     const int rem = r - n * hw;
     const int y = rem / g.Wg;
     const int x = rem - y * g.Wg;
-    ri.base = n * g.Hi * g.Wi;
     ri.ys = y * g.sy;
     ri.xs = x * g.sx;
+    ri.off = ((n * g.Hi + ri.ys) * g.Wi + ri.xs) * g.a_pitch;
     return ri;
 }
 
@@ -67,14 +67,15 @@ __device__ __forceinline__ int out_pixel(const ConvGeom& g, int r) {
 }
 
 // Load 4 channels of the source pixel of row `ri` for tap t; *ok says whether the tap is inside the image.
+// Branch-free: an outside tap loads element 0 (always mapped) and is zeroed by transform_a; a branch around
+// each load would make hipcc wait for every load separately.  Tap quantities are wave-uniform (SGPRs).
 __device__ __forceinline__ float4 load_a(const ConvGeom& g, const float* __restrict__ A, const RowInfo& ri, int t,
                                          int q, bool* ok) {
-    const int sy = ri.ys + g.dy[t], sx = ri.xs + g.dx[t];
-    *ok = ri.valid && sy >= 0 && sy < g.Hi && sx >= 0 && sx < g.Wi;
-    // branch-free: an outside tap loads pixel 0 (always mapped) and is zeroed by transform_a; a branch
-    // around each load would make hipcc wait for every load separately
-    const long pix = *ok ? (long)ri.base + sy * g.Wi + sx : 0;
-    return *reinterpret_cast<const float4*>(A + pix * g.a_pitch + g.a_col[t] + 4 * q);
+    const int dy = g.dy[t], dx = g.dx[t];
+    const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[t];
+    *ok = ri.valid & ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
+    const int off = *ok ? ri.off + delta : 0;
+    return *reinterpret_cast<const float4*>(A + off + 4 * q);
 }
 
 // previous layer's BatchNorm + ReLU folded into the operand load; padding stays exactly zero
@@ -321,6 +322,8 @@ static int check_geom(const ConvGeom& g) {
     CMVAE_REQUIRE(g.rows_total % (g.Hg * g.Wg) == 0, "conv geometry: rows not a multiple of the per-image grid");
     CMVAE_REQUIRE((g.Hg - 1) * g.oys + g.oy0 < g.Ho && (g.Wg - 1) * g.oxs + g.ox0 < g.Wo && g.oy0 >= 0 && g.ox0 >= 0,
                   "conv geometry: output grid exceeds the output image");
+    CMVAE_REQUIRE((long)(g.rows_total / (g.Hg * g.Wg)) * g.Hi * g.Wi * g.a_pitch < (1L << 31),
+                  "conv geometry: input larger than 2^31 elements");
     for (int t = 0; t < g.ntaps; ++t)
         CMVAE_REQUIRE(g.a_col[t] >= 0 && g.a_col[t] + 64 <= g.a_pitch && g.a_col[t] % 4 == 0,
                       "conv geometry: tap %d column window outside the input row", t);
@@ -337,7 +340,7 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
     g.Ho = c->Ho; g.Wo = c->Wo; g.oys = c->oys; g.oxs = c->oxs; g.oy0 = c->oy0; g.ox0 = c->ox0; g.ntaps = c->ntaps;
     g.a_pitch = c->a_pitch; g.o_pitch = c->o_pitch; g.w_pitch = c->w_pitch; g.w_tap_stride = c->w_tap_stride;
     g.w_nblk_stride = c->w_nblk_stride;
-    for (int t = 0; t < 16; ++t) { g.dy[t] = (signed char)c->dy[t]; g.dx[t] = (signed char)c->dx[t]; g.a_col[t] = c->a_col[t]; }
+    for (int t = 0; t < 16; ++t) { g.dy[t] = c->dy[t]; g.dx[t] = c->dx[t]; g.a_col[t] = c->a_col[t]; }
     return g;
 }
 
