@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cmvae_abi.h declares (no compute calls:
+there is no GPU here), the ctypes table covers them all, and the host surface mirrors the reference's."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'cmvae_abi.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(cmvae_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_entry_points():
+    syms = declared_symbols()
+    assert 'cmvae_unsup_prior' in syms and 'cmvae_conv_gemm' in syms and len(syms) >= 30
+
+
+def test_library_exports_every_declared_symbol():
+    from cmvae_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    unbound = [s for s in declared_symbols() if s not in _lib.SIGNATURES]
+    assert not unbound, unbound
+    assert _lib.lib.cmvae_abi_version() >= 1
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from cmvae_amd import _lib
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(ImportError):
+        _lib._load()
+
+
+def test_cpu_tensors_are_rejected():
+    from cmvae_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.unsup_prior(torch.zeros(1, 8, 64), torch.zeros(1, 2, dtype=torch.int64), None, 1)
+    with pytest.raises(RuntimeError):
+        ops.reparam_logq(torch.zeros(1, 2, 64), torch.zeros(1, 2, 64), torch.zeros(1, 2, 3, 64))
+
+
+def test_surface_matches_reference_signatures():
+    """Constructor argument names / defaults of omniglot/model.py:15-28 and mimgnet/model.py:12-25."""
+    from cmvae_amd.model import OmniglotGMVAE, FeatureGMVAE
+    sig = inspect.signature(OmniglotGMVAE.__init__).parameters
+    assert list(sig)[1:] == ['input_shape', 'unsupervised_em_iters', 'semisupervised_em_iters', 'fix_pi',
+                             'hidden_size', 'component_size', 'latent_size', 'train_mc_sample_size',
+                             'test_mc_sample_size', 'linear', 'eval_iter', 'laplace', 'gamma']
+    assert sig['linear'].default is False and sig['component_size'].default == 20
+    sigf = inspect.signature(FeatureGMVAE.__init__).parameters
+    assert list(sigf)[1:] == ['input_shape', 'unsupervised_em_iters', 'semisupervised_em_iters', 'fix_pi',
+                              'component_size', 'latent_size', 'train_mc_sample_size', 'test_mc_sample_size',
+                              'linear', 'laplace', 'gamma']
+    assert sigf['linear'].default is True and sigf['input_shape'].default == 512
+
+
+def test_state_dict_keys_and_param_count():
+    from cmvae_amd.model import OmniglotGMVAE, FeatureGMVAE
+    m = OmniglotGMVAE()
+    keys = set(m.state_dict())
+    for k in ('encoder.encoder.0.weight', 'encoder.encoder.13.running_var', 'q_z_given_H.0.mab.fc_q.weight',
+              'q_z_given_H.2.bias', 'causal.fc1.weight', 'causal.fc2.0.weight', 'causal.fc2.0.bias',
+              'proj.4.weight', 'decoder.decoder.9.bias', 'decoder.decoder.7.num_batches_tracked',
+              'log_norm_constant', 'log_2', 'uniform_pi'):
+        assert k in keys, k
+    assert sum(p.numel() for p in m.parameters()) == 1140545
+    assert m.state_dict()['log_norm_constant'].dtype == torch.float64
+    f = FeatureGMVAE(input_shape=256)
+    assert 'causal.A' in f.state_dict() and 'log_2' not in f.state_dict()
+    assert tuple(f.state_dict()['causal.A'].shape) == (64, 64)

@@ -1,0 +1,86 @@
+"""CPU, world_size 2 over gloo: the episode-sharded data-parallel host logic (cmvae_amd/dist.py) gives the
+same numbers as one process on the whole meta-batch — BatchNorm statistics all-reduce (C2), flat gradient
+all-reduce (C1), EM-seed slicing from the shared numpy stream."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net():
+    from cmvae_amd.module import EpisodeBatchNorm2d
+    torch.manual_seed(3)
+    return nn.Sequential(nn.Conv2d(1, 4, 3, 1, 1), EpisodeBatchNorm2d(4), nn.ReLU(), nn.Conv2d(4, 2, 3, 1, 1),
+                         EpisodeBatchNorm2d(2))
+
+
+def _data():
+    g = torch.Generator().manual_seed(9)
+    return torch.randn(8, 1, 6, 6, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from cmvae_amd import dist as cdist
+    r, w = cdist.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    net = _net().train()
+    flat = cdist.FlatGrads(net.parameters())
+    x = _data()[cdist.shard_slice(8)]
+    flat.zero()
+    y = net(x)
+    loss = (y ** 2).mean()                       # a mean over an equal-sized shard
+    loss.backward()
+    flat.allreduce()
+    np.random.seed(77)
+    idx = cdist.draw_em_init(50, 3, 8)
+    out[rank] = dict(y=y.detach(), grad=flat.flat.clone(), rm=net[1].running_mean.clone(),
+                     rv=net[4].running_var.clone(), idx=idx, after=np.random.rand())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    # single process on the whole meta-batch
+    from cmvae_amd import dist as cdist
+    net = _net().train()
+    flat = cdist.FlatGrads(net.parameters())
+    flat.zero()
+    y = net(_data())
+    (y ** 2).mean().backward()
+    got_y = torch.cat([out[0]['y'], out[1]['y']], 0)
+    assert torch.allclose(got_y, y.detach(), atol=1e-5)
+    for r in range(world):
+        assert torch.allclose(out[r]['grad'], flat.flat, atol=1e-5), (out[r]['grad'] - flat.flat).abs().max()
+        assert torch.allclose(out[r]['rm'], net[1].running_mean, atol=1e-6)
+        assert torch.allclose(out[r]['rv'], net[4].running_var, atol=1e-6)
+    # EM seeds: every rank drew the global stream and kept its own slice
+    np.random.seed(77)
+    ref = np.stack([np.random.choice(50, 3, replace=False) for _ in range(8)], 0)
+    after = np.random.rand()
+    assert np.array_equal(np.concatenate([out[0]['idx'], out[1]['idx']], 0), ref)
+    assert out[0]['after'] == after and out[1]['after'] == after
+
+
+def test_shard_slice_rejects_uneven_batches():
+    from cmvae_amd import dist as cdist
+    import pytest
+    with pytest.raises(ValueError):
+        cdist.shard_slice(7, 0, 2)
+    assert cdist.shard_slice(8, 1, 4) == slice(2, 4)

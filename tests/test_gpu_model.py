@@ -156,3 +156,29 @@ def test_numpy_stream_matches_reference_order(device):
     got = model._draw_init_idx(B, S * M, device).cpu().numpy()
     assert np.array_equal(got, expect)
     assert np.random.rand() == after
+
+
+@pytest.mark.parametrize('name', ['omniglot_nonlinear', 'omniglot_linear', 'feat_linear', 'feat_nonlinear'])
+def test_hip_path_matches_golden_vectors(device, name):
+    """The committed fixtures (tests/golden/*.npz, made by tools/make_golden.py from the oracle)."""
+    import os
+    from tools.make_golden import CASES, case_inputs
+    c = CASES[name]
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', name + '.npz'))
+    model, _ = build_pair(c['variant'], K=c['K'], M=c['M'], iters=3, linear=c['linear'], seed=5)
+    X, eps, idx, y_tr = case_inputs(c)
+    model.to(device).train()
+    ex = {}
+    out = model(X.to(device), 0.1, 0.1, 1e-4, eps=eps.to(device), init_idx=torch.from_numpy(idx).to(device),
+                extras=ex)
+    for i, k in ((1, 'rec'), (2, 'kl'), (3, 'h_aug')):
+        assert abs(float(out[i]) - float(gold[k])) <= RTOL * abs(float(gold[k])) + 1e-7, k
+    assert rel_err(ex['mu_k'], torch.from_numpy(gold['mu_k'])) < RTOL
+    assert rel_err(ex['pi_k'], torch.from_numpy(gold['pi_k'])) < RTOL
+    assert rel_err(ex['log_p_z'].reshape(-1), torch.from_numpy(gold['log_p_z']).reshape(-1)) < RTOL
+    # the oracle's fixture was made with BatchNorm running statistics at their initial values
+    model2, _ = build_pair(c['variant'], K=c['K'], M=c['M'], iters=3, linear=c['linear'], seed=5)
+    model2.to(device).eval()
+    K = c['K']
+    y = model2.prediction(X[:, :K].to(device), y_tr.to(device), X[:, K:].to(device), eps=eps.to(device))
+    assert np.array_equal(y.cpu().numpy(), gold['y_pred'])
