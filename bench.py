@@ -59,7 +59,7 @@ def event_time_ms(fn, iters, stream):
 
 
 def roofline_em_pass(device):
-    """Dominant hand-written HBM-bound kernel: the fused E-step/M-step pass (em_pass_kernel).
+    """HBM-bound kernel of the EM loop: the fused E-step/M-step pass (em_pass_kernel).
     Algorithmic bytes per launch = B*(N*D*4 + K*(2D+2)*4)  (SURVEY.md §8d)."""
     from cmvae_amd import ops
     B, N, K, D = B_PER_GPU, SAMPLE * MC, WAY, 64
@@ -74,7 +74,54 @@ def roofline_em_pass(device):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {'kernel': 'em_pass_kernel', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-            'launch_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes}
+            'launch_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes,
+            'note': 'back-to-back launches from Python: includes host launch gaps'}
+
+
+def useful_flops(g, ncb):
+    """Algorithmic FLOPs of one gather-GEMM launch: 2 * 64 * 64 * (in-image taps over all rows) * column blocks
+    (taps that fall in the zero padding are not counted)."""
+    n_img = g.rows_total // (g.Hg * g.Wg)
+    taps = 0
+    for t in range(g.ntaps):
+        ny = sum(1 for y in range(g.Hg) if 0 <= y * g.sy + g.dy[t] < g.Hi)
+        nx = sum(1 for x in range(g.Wg) if 0 <= x * g.sx + g.dx[t] < g.Wi)
+        taps += ny * nx
+    return 2.0 * 64 * 64 * taps * n_img * ncb
+
+
+def roofline_conv_gemm(step_fn):
+    """Dominant kernel of the step: conv_gemm_kernel (fp32 MFMA gather-GEMM: all decoder / encoder convs and
+    their data gradients).  Every launch of one extra, untimed training step is bracketed by HIP events on
+    the launch stream; achieved = sum of algorithmic FLOPs / sum of launch durations."""
+    from cmvae_amd import conv
+    rec = []
+    orig = conv.conv_gemm
+
+    def timed(g, A, Wt, out, bias=None, a_scale=None, a_shift=None, act=0, n_col_blocks=1, stats=False):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(g, A, Wt, out, bias=bias, a_scale=a_scale, a_shift=a_shift, act=act, n_col_blocks=n_col_blocks,
+                 stats=stats)
+        e1.record()
+        rec.append((e0, e1, useful_flops(g, n_col_blocks)))
+        return r
+
+    conv.conv_gemm = timed
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        conv.conv_gemm = orig
+    total_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+    total_flops = sum(f for _, _, f in rec)
+    achieved = total_flops / (total_ms * 1e-3) / 1e12
+    return {'kernel': 'conv_gemm_kernel', 'bound': 'mfma', 'achieved': round(achieved, 2),
+            'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+            'traffic': None, 'launches_per_step': len(rec), 'avg_launch_us': round(total_ms * 1e3 / len(rec), 1),
+            'algorithmic_gflop_per_launch': round(total_flops / len(rec) / 1e9, 2),
+            'share_of_step_ms': round(total_ms, 2)}
 
 
 def cpu_baseline(threads):
@@ -203,6 +250,9 @@ def main():
         eval_rates['%dshot' % shot] = round(B_PER_GPU * world * args.eval_calls / edt, 2)
         note('eval %d-shot done' % shot)
 
+    # roofline of the dominant kernel: one extra, untimed, instrumented training step (all ranks take part:
+    # the step contains the BatchNorm-statistics and gradient all-reduces)
+    roof = roofline_conv_gemm(lambda: step(0))
     if rank == 0:
         out = {
             'metric': 'train episodes/sec (whole node) + eval EM episodes/sec, Omniglot 20-way',
@@ -215,8 +265,9 @@ def main():
             'eval_episodes_per_s': eval_rates,
             'final_losses': {'rec': losses[0], 'kl': losses[1], 'h_aug': losses[2]},
         }
-        out['roofline'] = roofline_em_pass(device)
-        note('roofline micro-measure done; starting cpu baseline')
+        out['roofline'] = roof
+        out['roofline_other'] = [roofline_em_pass(device)]
+        note('roofline measurements done; starting cpu baseline')
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '16')))
             cb = cpu_baseline(threads)

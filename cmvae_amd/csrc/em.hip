@@ -637,8 +637,8 @@ static int pick_tiles_per_block(int B, int N) {
     const int tiles_ep = (N + TR - 1) / TR;
     const long total = (long)tiles_ep * B;
     int tpb = (int)(total / 384);
-    if (tpb < 1) tpb = 1;
     if (tpb > tiles_ep) tpb = tiles_ep;
+    if (tpb < 1) tpb = 1;
     return tpb;
 }
 static int nblk_for(int N, int tpb) {

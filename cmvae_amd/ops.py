@@ -93,6 +93,8 @@ def unsup_prior(z, init_idx, causal, iters, fix_pi=False, gamma1=1.0):
     if z.dim() != 3 or z.shape[-1] != D:
         raise RuntimeError('cmvae_amd: z must be [B,N,64]')
     B, N, _ = z.shape
+    if B < 1 or N < 1:
+        raise RuntimeError('cmvae_amd: unsup_prior needs at least one episode and one latent')
     init_idx = _req(init_idx, 'init_idx', torch.int64)
     if init_idx.dim() != 2 or init_idx.shape[0] != B:
         raise RuntimeError('cmvae_amd: init_idx must be [B,K]')
@@ -128,6 +130,8 @@ def semi_prior(uz, sz, y, K, causal, iters, gamma1=1.0):
         raise RuntimeError('cmvae_amd: uz/sz must be [B,N,64] with equal B')
     B, Nu, _ = uz.shape
     Ns = sz.shape[1]
+    if B < 1 or Nu < 1 or Ns < 1:
+        raise RuntimeError('cmvae_amd: semi_prior needs at least one episode, one query and one support latent')
     if tuple(y.shape) != (B, Ns):
         raise RuntimeError('cmvae_amd: y must be [B,Ns] int64 labels')
     if not (1 <= K <= 32):

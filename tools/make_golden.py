@@ -19,8 +19,8 @@ from tests.helpers import build_pair, omniglot_batch, feature_batch   # noqa: E4
 CASES = {
     'omniglot_nonlinear': dict(variant='omniglot', linear=False, K=3, M=4, B=2, S=6),
     'omniglot_linear': dict(variant='omniglot', linear=True, K=3, M=4, B=2, S=6),
-    'feat_linear': dict(variant='feat', linear=True, K=5, M=8, B=2, S=5),
-    'feat_nonlinear': dict(variant='feat', linear=False, K=5, M=8, B=2, S=5),
+    'feat_linear': dict(variant='feat', linear=True, K=5, M=8, B=2, S=9),
+    'feat_nonlinear': dict(variant='feat', linear=False, K=5, M=8, B=2, S=9),
 }
 
 
