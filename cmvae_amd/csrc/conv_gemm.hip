@@ -299,18 +299,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            WgradOut o, float* __restrict__ dW,
                                                            const float* __restrict__ db_part,
                                                            float* __restrict__ db, int accumulate_db) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < NT * 4096) {
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += part[(long)b * NT * 4096 + e];
-        const int t = e >> 12, ci = (e >> 6) & 63, co = e & 63;
-        dW[o.tap_off[t] + ci * o.s_ci + co * o.s_co] = s;
+    // 64 consecutive elements x 4 groups of partial blocks per workgroup; fixed summation order
+    __shared__ float red[4 * 64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + c;
+    const bool is_db = blockIdx.x == gridDim.x - 1 && db != nullptr;     // last workgroup: the bias gradient
+    float s0 = 0.f, s1 = 0.f;
+    if (!is_db) {
+        if (e < NT * 4096) {
+            int b = g;
+            for (; b + 4 < nblk; b += 8) {
+                s0 += part[(long)b * NT * 4096 + e];
+                s1 += part[(long)(b + 4) * NT * 4096 + e];
+            }
+            if (b < nblk) s0 += part[(long)b * NT * 4096 + e];
+        }
+    } else {
+        for (int b = g; b < nblk; b += 4) s0 += db_part[(long)b * 64 + c];
     }
-    if (db && blockIdx.x == 0 && threadIdx.x < 64) {
-        float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += db_part[(long)b * 64 + threadIdx.x];
-        if (accumulate_db) s += db[threadIdx.x];
-        db[threadIdx.x] = s;
+    red[g * 64 + c] = s0 + s1;
+    __syncthreads();
+    if (g != 0) return;
+    const float s = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+    if (!is_db) {
+        if (e < NT * 4096) {
+            const int t = e >> 12, ci = (e >> 6) & 63, co = e & 63;
+            dW[o.tap_off[t] + ci * o.s_ci + co * o.s_co] = s;
+        }
+    } else {
+        db[c] = accumulate_db ? db[c] + s : s;
     }
 }
 
@@ -408,7 +425,7 @@ extern "C" int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, con
         WgradOut o{};
         for (int t = 0; t < nt; ++t) o.tap_off[t] = tap_off_host[t0 + t];
         o.s_ci = s_ci; o.s_co = s_co;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nt * 4096 + 255) / 256), dim3(256), 0, st, part, nblk, nt, o, dW,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nt * 64 + (dbp ? 1 : 0)), dim3(256), 0, st, part, nblk, nt, o, dW,
                            dbp, dbp ? db : nullptr, accumulate_db);
         if (int e = check_launch("wgrad_reduce_kernel")) return e;
     }

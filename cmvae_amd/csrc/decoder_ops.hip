@@ -9,20 +9,29 @@ namespace cmvae {
 constexpr int C = 64;
 
 // ------------------------------------------------------------------ out[L] = sum_b part[b][L]
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nblk, int L,
-                                                            float* __restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= L) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += part[(long)b * L + e];
-        s1 += part[(long)(b + 1) * L + e];
-        s2 += part[(long)(b + 2) * L + e];
-        s3 += part[(long)(b + 3) * L + e];
+// 64 columns x 16 row groups per block; fixed summation order (reproducible)
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ part, int nblk, int L,
+                                                             float* __restrict__ out) {
+    __shared__ float red[16 * 64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < L) {
+        int b = g;
+        for (; b + 16 < nblk; b += 32) {
+            s0 += part[(long)b * L + e];
+            s1 += part[(long)(b + 16) * L + e];
+        }
+        if (b < nblk) s0 += part[(long)b * L + e];
     }
-    for (; b < nblk; ++b) s0 += part[(long)b * L + e];
-    out[e] = (s0 + s1) + (s2 + s3);
+    red[g * 64 + c] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && e < L) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r * 64 + c];
+        out[e] = s;
+    }
 }
 
 // ------------------------------------------------------------------ BN forward finalize
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restric
 
 static int rowpass_grid(long rows) {
     long g = (rows + 15) / 16;
-    if (g > 2048) g = 2048;
+    if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -314,7 +323,7 @@ using namespace cmvae;
 
 extern "C" int cmvae_colsum_reduce(const float* part, int nblk, int L, float* out, void* stream) {
     CMVAE_REQUIRE(part && out && nblk >= 1 && L >= 1, "cmvae_colsum_reduce: bad arguments");
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((L + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nblk, L, out);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((L + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, nblk, L, out);
     return check_launch("colsum_reduce_kernel");
 }
 

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 
 static int rp_grid(long rows) {
     long g = (rows + 15) / 16;
-    if (g > 2048) g = 2048;
+    if (g > 1024) g = 1024;
     return g < 1 ? 1 : (int)g;
 }
 
