@@ -30,9 +30,11 @@ __device__ __forceinline__ float expm1_fast(float x) {
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1_fast(x); }
 
 // ------------------------------------------------------------------ causal residual of ONE row
-// xs[64] (LDS) -> es[64] (LDS) = xs - mask(xs).  Whole 256-thread block participates;
+// xs[64] (LDS) -> es[64] (LDS) = xs - mask(xs).  The whole block of NW waves participates (each wave owns
+// 64/NW output dims = 2048/NW hidden units, so NW*8 weight loads are in flight per CU);
 // caller must __syncthreads() before reading es.
-__device__ __forceinline__ void causal_row_256(const float* xs, float* es, const cmvae_causal& c) {
+template <int NW>
+__device__ __forceinline__ void causal_row(const float* xs, float* es, const cmvae_causal& c) {
     const int tid = threadIdx.x;
     if (c.linear) {
         if (tid < D) {
@@ -47,8 +49,9 @@ __device__ __forceinline__ void causal_row_256(const float* xs, float* es, const
     const int q = lane & 15;     // which float4 of the 64-wide fc1 row
     const int sub = lane >> 4;   // which of the 4 hidden units of a 1-KiB packet
     const float4 xv = reinterpret_cast<const float4*>(xs)[q];
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * w + jj;
+#pragma unroll 2
+    for (int jj = 0; jj < 64 / NW; ++jj) {
+        const int j = (64 / NW) * w + jj;
         float acc = 0.f;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -86,7 +89,7 @@ __device__ __forceinline__ float prior_term_wave0(const float* es, float log_tau
 }
 
 // ------------------------------------------------------------------ kernel: causal on rows
-__global__ __launch_bounds__(256) void causal_rows_kernel(const float* __restrict__ x, int rows, cmvae_causal c,
+__global__ __launch_bounds__(1024) void causal_rows_kernel(const float* __restrict__ x, int rows, cmvae_causal c,
                                                           const float* __restrict__ pi,
                                                           const float* __restrict__ tau,
                                                           float* __restrict__ eps, float* __restrict__ logw) {
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void causal_rows_kernel(const float* __restric
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         if (threadIdx.x < D) xs[threadIdx.x] = x[(size_t)r * D + threadIdx.x];
         __syncthreads();
-        causal_row_256(xs, es, c);
+        causal_row<16>(xs, es, c);
         __syncthreads();
         if (threadIdx.x < D) {
             if (eps) eps[(size_t)r * D + threadIdx.x] = es[threadIdx.x];
@@ -113,89 +116,92 @@ __global__ __launch_bounds__(256) void causal_rows_kernel(const float* __restric
 constexpr int CT_LD = 68;   // C^T leading dim (float4-aligned, conflict-free float4 reads)
 constexpr int MS_LD = 65;
 
-__global__ __launch_bounds__(256) void gram_inverse_kernel(const float* __restrict__ logvar, float s0,
-                                                           cmvae_causal c, float* __restrict__ out) {
+// 1024 threads: 16 waves share the 2048 hidden units (C), a 2x2 Gram tile per thread, 4 Gauss-Jordan
+// columns per thread.
+__global__ __launch_bounds__(1024) void gram_inverse_kernel(const float* __restrict__ logvar, float s0,
+                                                            cmvae_causal c, float* __restrict__ out) {
     __shared__ __align__(16) float CT[D * CT_LD];   // CT[j][i] = C[i][j]
-    __shared__ float Ms[D * MS_LD];
-    __shared__ float prow[D];
-    __shared__ float pcol[D];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ __align__(16) float Ms[D * MS_LD];
+    __shared__ float prow2[2 * D];                  // double-buffered pivot row / column: one barrier per step
+    __shared__ float pcol2[2 * D];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;     // w in [0,16)
     const int m = blockIdx.x;
     // lane = input dim i
     float s = s0;
     if (logvar) s = expf(0.5f * logvar[(size_t)m * D + lane]) * s0;
     if (c.linear) {
         // C = S (I - A): C[i][j] = s_i (delta_ij - A[i][j])
-        for (int j = w; j < D; j += 4) {
+        for (int j = w; j < D; j += 16) {
             float a = c.W[lane * D + j];
             CT[j * CT_LD + lane] = s * ((lane == j ? 1.f : 0.f) - a);
         }
     } else {
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = 16 * w + jj;
-            float acc = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * w + jj;
+            float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll 8
-            for (int mm = 0; mm < M1; ++mm) {
+            for (int mm = 0; mm < M1; mm += 2) {
                 const int u = 32 * j + mm;
-                float pre = fmaf(s, c.W[(size_t)u * D + lane], c.b1[u]);
-                acc = fmaf(elu_f(pre), c.w2[u], acc);
+                const float pre0 = fmaf(s, c.W[(size_t)u * D + lane], c.b1[u]);
+                const float pre1 = fmaf(s, c.W[(size_t)(u + 1) * D + lane], c.b1[u + 1]);
+                acc0 = fmaf(elu_f(pre0), c.w2[u], acc0);
+                acc1 = fmaf(elu_f(pre1), c.w2[u + 1], acc1);
             }
-            CT[j * CT_LD + lane] = (lane == j ? s : 0.f) - (acc + c.b2[j]);
+            CT[j * CT_LD + lane] = (lane == j ? s : 0.f) - ((acc0 + acc1) + c.b2[j]);
         }
     }
     __syncthreads();
-    // M = I + C C^T, 4x4 register tile per thread
+    // M = I + C C^T, 2x2 register tile per thread
     {
-        const int ti = tid >> 4, tk = tid & 15;
-        float acc[4][4] = {};
+        const int ti = tid >> 5, tk = tid & 31;
+        float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+#pragma unroll 8
         for (int j = 0; j < D; ++j) {
-            const float4 a = *reinterpret_cast<const float4*>(&CT[j * CT_LD + 4 * ti]);
-            const float4 b = *reinterpret_cast<const float4*>(&CT[j * CT_LD + 4 * tk]);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-            const float bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[p][q] = fmaf(av[p], bv[q], acc[p][q]);
+            const float2 a = *reinterpret_cast<const float2*>(&CT[j * CT_LD + 2 * ti]);
+            const float2 b = *reinterpret_cast<const float2*>(&CT[j * CT_LD + 2 * tk]);
+            a00 = fmaf(a.x, b.x, a00); a01 = fmaf(a.x, b.y, a01);
+            a10 = fmaf(a.y, b.x, a10); a11 = fmaf(a.y, b.y, a11);
         }
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = 4 * ti + p, k = 4 * tk + q;
-                Ms[i * MS_LD + k] = acc[p][q] + (i == k ? 1.f : 0.f);
-            }
+        const int i = 2 * ti, k = 2 * tk;
+        Ms[i * MS_LD + k] = a00 + (i == k ? 1.f : 0.f);
+        Ms[i * MS_LD + k + 1] = a01;
+        Ms[(i + 1) * MS_LD + k] = a10;
+        Ms[(i + 1) * MS_LD + k + 1] = a11 + (i == k ? 1.f : 0.f);
     }
     __syncthreads();
-    // in-place Gauss-Jordan (SPD, eigenvalues >= 1: no pivoting needed)
-    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    // in-place Gauss-Jordan (SPD, eigenvalues >= 1: no pivoting needed); thread = (row r, 4 columns)
+    const int r = tid >> 4, c0 = (tid & 15) * 4;
+    float own[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) own[cc] = Ms[r * MS_LD + c0 + cc];
     for (int p = 0; p < D; ++p) {
-        if (tid < D) {
-            prow[tid] = Ms[p * MS_LD + tid];
-            pcol[tid] = Ms[tid * MS_LD + p];
+        float* prow = prow2 + (p & 1) * D;
+        float* pcol = pcol2 + (p & 1) * D;
+        // publish pivot row and pivot column from the registers that own them
+        if (r == p) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) prow[c0 + cc] = own[cc];
+        }
+        if ((p >> 2) == (tid & 15)) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                if (cc == (p & 3)) pcol[r] = own[cc];
         }
         __syncthreads();
         const float dinv = 1.f / prow[p];
-        const float f = pcol[r];
+        const float fd = pcol[r] * dinv;
         if (r == p) {
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) {
-                const int col = c0 + cc;
-                Ms[r * MS_LD + col] = (col == p) ? dinv : prow[col] * dinv;
-            }
+            for (int cc = 0; cc < 4; ++cc) own[cc] = (c0 + cc == p) ? dinv : own[cc] * dinv;
         } else {
-            const float fd = f * dinv;
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) {
-                const int col = c0 + cc;
-                const float old = Ms[r * MS_LD + col];
-                Ms[r * MS_LD + col] = (col == p) ? -fd : fmaf(-fd, prow[col], old);
-            }
+            for (int cc = 0; cc < 4; ++cc) own[cc] = (c0 + cc == p) ? -fd : fmaf(-fd, prow[c0 + cc], own[cc]);
         }
-        __syncthreads();
     }
     float* o = out + (size_t)m * D * D;
-    for (int e = tid; e < D * D; e += 256) o[e] = Ms[(e >> 6) * MS_LD + (e & 63)];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) o[r * D + c0 + cc] = own[cc];
 }
 
 // ------------------------------------------------------------------ the E/M pass
@@ -403,10 +409,12 @@ struct FinArgs {
     float* pi; float* mu; float* logvar; float* tau; float* logw;
 };
 
-__global__ __launch_bounds__(256) void em_finalize_kernel(FinArgs a) {
-    __shared__ float red[4 * D];
-    __shared__ float red2[4 * D];
-    __shared__ float nred[8 * 32];
+constexpr int FW = 16;      // waves per finalize block
+
+__global__ __launch_bounds__(1024) void em_finalize_kernel(FinArgs a) {
+    __shared__ float red[FW * D];
+    __shared__ float red2[FW * D];
+    __shared__ float nred[32 * 32];
     __shared__ __align__(16) float ms[D];
     __shared__ __align__(16) float xs[D];
     __shared__ __align__(16) float es[D];
@@ -424,15 +432,15 @@ __global__ __launch_bounds__(256) void em_finalize_kernel(FinArgs a) {
     } else {
         // ---- N_k' for every component (needed for pi), fixed-order reduction
         {
-            const int kk = tid & 31, ch = tid >> 5;   // 8 chunks of blocks
+            const int kk = tid & 31, ch = tid >> 5;   // 32 chunks of blocks
             float acc = 0.f;
-            for (int i = ch; i < a.nblk; i += 8) acc += a.part_N[((size_t)b * a.nblk + i) * 32 + kk];
+            for (int i = ch; i < a.nblk; i += 32) acc += a.part_N[((size_t)b * a.nblk + i) * 32 + kk];
             nred[ch * 32 + kk] = acc;
         }
         // ---- S1 (and S2) for this component
         {
             float acc = 0.f, acc2 = 0.f;
-            for (int i = w; i < a.nblk; i += 4) {
+            for (int i = w; i < a.nblk; i += FW) {
                 const size_t o = (((size_t)b * a.nblk + i) * K + k) * D + lane;
                 acc += a.part_S1[o];
                 if (a.part_S2) acc2 += a.part_S2[o];
@@ -444,13 +452,13 @@ __global__ __launch_bounds__(256) void em_finalize_kernel(FinArgs a) {
         if (tid < 32) {
             float acc = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) acc += nred[ch * 32 + tid];
+            for (int ch = 0; ch < 32; ++ch) acc += nred[ch * 32 + tid];
             nall[tid] = acc;
         }
         __syncthreads();
         uN = nall[k];
-        S1 = (red[lane] + red[D + lane]) + (red[2 * D + lane] + red[3 * D + lane]);
-        S2 = (red2[lane] + red2[D + lane]) + (red2[2 * D + lane] + red2[3 * D + lane]);
+#pragma unroll
+        for (int ww = 0; ww < FW; ++ww) { S1 += red[ww * D + lane]; S2 += red2[ww * D + lane]; }
         if (!a.semi) {
             // N guard, then pi from the guarded N (omniglot/model.py:192-207)
             float ntot = 0.f;
@@ -471,13 +479,16 @@ __global__ __launch_bounds__(256) void em_finalize_kernel(FinArgs a) {
     {
         const float* Mi = a.minv + (a.minv_stride ? ((size_t)b * K + k) * a.minv_stride : 0);
         float acc = 0.f;
-#pragma unroll 4
-        for (int i = 16 * w; i < 16 * w + 16; ++i) acc = fmaf(ms[i], Mi[i * D + lane], acc);
+#pragma unroll
+        for (int i = 4 * w; i < 4 * w + 4; ++i) acc = fmaf(ms[i], Mi[i * D + lane], acc);
+        __syncthreads();             // everyone is done reading red/red2 as partial sums
         red[w * D + lane] = acc;
     }
     __syncthreads();
     if (tid < D) {
-        const float mean = (red[tid] + red[D + tid]) + (red[2 * D + tid] + red[3 * D + tid]);
+        float mean = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FW; ++ww) mean += red[ww * D + tid];
         xs[tid] = mean;
         a.mu[((size_t)b * K + k) * D + tid] = mean;
         if (a.semi) {
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(256) void em_finalize_kernel(FinArgs a) {
     }
     __syncthreads();
     // ---- prior term of the next E-step: log pi + glp(causal(mean), log tau)
-    causal_row_256(xs, es, a.c);
+    causal_row<FW>(xs, es, a.c);
     __syncthreads();
     if (tid < D) {
         const float p = prior_term_wave0(es, logf(a.tau_new));
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(const float* __re
 static int pick_tiles_per_block(int B, int N) {
     const int tiles_ep = (N + TR - 1) / TR;
     const long total = (long)tiles_ep * B;
-    int tpb = (int)(total / 384);
+    int tpb = (int)(total / 256);
     if (tpb > tiles_ep) tpb = tiles_ep;
     if (tpb < 1) tpb = 1;
     return tpb;
@@ -720,7 +731,7 @@ extern "C" int cmvae_causal_rows(const float* x, int rows, const cmvae_causal* c
     CMVAE_REQUIRE(!logw || (pi && tau), "cmvae_causal_rows: logw needs pi and tau");
     if (rows == 0) return 0;
     const int grid = rows < 4096 ? rows : 4096;
-    hipLaunchKernelGGL(causal_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, rows, *c, pi, tau, eps,
+    hipLaunchKernelGGL(causal_rows_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, x, rows, *c, pi, tau, eps,
                        logw);
     return check_launch("causal_rows_kernel");
 }
@@ -730,7 +741,7 @@ extern "C" int cmvae_gram_inverse(const float* logvar, float s0, int nmat, const
     if (int e = check_causal(c)) return e;
     CMVAE_REQUIRE(out && nmat >= 0, "cmvae_gram_inverse: bad arguments");
     if (nmat == 0) return 0;
-    hipLaunchKernelGGL(gram_inverse_kernel, dim3(nmat), dim3(256), 0, (hipStream_t)stream, logvar, s0, *c, out);
+    hipLaunchKernelGGL(gram_inverse_kernel, dim3(nmat), dim3(1024), 0, (hipStream_t)stream, logvar, s0, *c, out);
     return check_launch("gram_inverse_kernel");
 }
 
@@ -752,11 +763,11 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
     hipStream_t st = (hipStream_t)stream;
     const int tpb = pick_tiles_per_block(B, N), nblk = nblk_for(N, tpb);
     // initial inverse (tau0 = 1) and the loop inverse (tau = gamma1); both data independent
-    hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(256), 0, st, nullptr, 1.0f, *c, w.minv0);
+    hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(1024), 0, st, nullptr, 1.0f, *c, w.minv0);
     if (int e = check_launch("gram_inverse_kernel")) return e;
     const float* minv_loop = w.minv0;
     if (gamma1 != 1.0f) {
-        hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(256), 0, st, nullptr, gamma1, *c, w.minv);
+        hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(1024), 0, st, nullptr, gamma1, *c, w.minv);
         if (int e = check_launch("gram_inverse_kernel")) return e;
         minv_loop = w.minv;
     }
@@ -764,7 +775,7 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
     f.z = z; f.init_idx = init_idx; f.N = N; f.K = K; f.fix_pi = fix_pi; f.semi = 0; f.init = 1;
     f.minv = w.minv0; f.minv_stride = 0; f.tau_new = 1.0f; f.c = *c;
     f.pi = pi; f.mu = mu; f.logvar = nullptr; f.tau = tau; f.logw = logw;
-    hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
     if (int e = check_launch("em_finalize_kernel(init)")) return e;
     PassArgs p{};
     p.z = z; p.mu = mu; p.logw = logw; p.part_N = w.part_N; p.part_S1 = w.part_S1;
@@ -773,7 +784,7 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
     f.minv = minv_loop; f.tau_new = gamma1;
     for (int it = 0; it < iters; ++it) {
         if (int e = launch_pass(p, B, st)) return e;
-        hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
         if (int e = check_launch("em_finalize_kernel")) return e;
     }
     return 0;
@@ -819,13 +830,13 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
     hipLaunchKernelGGL(sup_reduce_kernel, dim3(K, B), dim3(64), 0, st, w.spart_N, w.spart_S1, w.spart_S2, snblk, K,
                        w.sN, w.sS1, w.sS2);
     if (int e = check_launch("sup_reduce_kernel")) return e;
-    hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(256), 0, st, nullptr, 1.0f, *c, w.minv0);
+    hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(1024), 0, st, nullptr, 1.0f, *c, w.minv0);
     if (int e = check_launch("gram_inverse_kernel")) return e;
     FinArgs f{};
     f.K = K; f.fix_pi = 1; f.semi = 1; f.init = 1; f.sN = w.sN; f.sS1 = w.sS1; f.sS2 = w.sS2;
     f.minv = w.minv0; f.minv_stride = 0; f.tau_new = 1.0f; f.c = *c;
     f.pi = pi; f.mu = mu; f.logvar = logvar; f.tau = tau; f.logw = logw;
-    hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
     if (int e = check_launch("em_finalize_kernel(semi init)")) return e;
     PassArgs p{};
     p.z = uz; p.mu = mu; p.logw = logw; p.part_N = w.part_N; p.part_S1 = w.part_S1; p.part_S2 = w.part_S2;
@@ -834,10 +845,10 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
     f.minv = w.minv; f.minv_stride = (size_t)D * D; f.tau_new = gamma1;
     for (int it = 0; it < iters; ++it) {
         // inverse from the incoming logvar and tau = gamma1 (omniglot/model.py:259-265)
-        hipLaunchKernelGGL(gram_inverse_kernel, dim3(B * K), dim3(256), 0, st, logvar, gamma1, *c, w.minv);
+        hipLaunchKernelGGL(gram_inverse_kernel, dim3(B * K), dim3(1024), 0, st, logvar, gamma1, *c, w.minv);
         if (int e = check_launch("gram_inverse_kernel")) return e;
         if (int e = launch_pass(p, B, st)) return e;
-        hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
         if (int e = check_launch("em_finalize_kernel")) return e;
     }
     return 0;
