@@ -38,22 +38,50 @@ struct ConvGeom {
 
 struct RowInfo {
     int off;                  // element offset of source pixel (image, y*sy, x*sx): pixel * a_pitch
-    int ys, xs;               // y*sy, x*sx
-    bool valid;
+    int ys, xs;               // y*sy, x*sx; a row past rows_total gets ys = INVALID_YS so that no tap is inside
+};
+constexpr int INVALID_YS = -(1 << 24);
+
+// floor(a / d) for 0 <= a < 2^21 through the fp32 reciprocal of d (exact in that range; check_geom bounds Hg*Wg)
+__device__ __forceinline__ int small_div(int a, float inv_d) { return (int)(((float)a + 0.5f) * inv_d); }
+
+struct RowDecoder {
+    float inv_hw, inv_wg;
+    int hw, wg;
+    __device__ __forceinline__ RowDecoder(const ConvGeom& g) : hw(g.Hg * g.Wg), wg(g.Wg) {
+        inv_hw = 1.0f / (float)hw;
+        inv_wg = 1.0f / (float)g.Wg;
+    }
+    // rows r0 + step*e, e = 0..N-1 -> (image, y, x) with one integer division
+    template <int N, typename F>
+    __device__ __forceinline__ void decode(int r0, int step, F&& f) const {
+        const int n0 = r0 / hw;
+        const int rem0 = r0 - n0 * hw;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            int rem = rem0 + step * e;
+            const int dn = small_div(rem, inv_hw);
+            rem -= dn * hw;
+            const int y = small_div(rem, inv_wg);
+            f(e, n0 + dn, y, rem - y * wg);
+        }
+    }
 };
 
-__device__ __forceinline__ RowInfo row_info(const ConvGeom& g, int r) {
+__device__ __forceinline__ RowInfo make_row(const ConvGeom& g, int r, int n, int y, int x) {
     RowInfo ri;
-    ri.valid = r < g.rows_total;
+    ri.ys = r < g.rows_total ? y * g.sy : INVALID_YS;
+    ri.xs = x * g.sx;
+    ri.off = ((n * g.Hi + y * g.sy) * g.Wi + ri.xs) * g.a_pitch;
+    return ri;
+}
+
+__device__ __forceinline__ RowInfo row_info(const ConvGeom& g, int r) {
     const int hw = g.Hg * g.Wg;
     const int n = r / hw;
     const int rem = r - n * hw;
     const int y = rem / g.Wg;
-    const int x = rem - y * g.Wg;
-    ri.ys = y * g.sy;
-    ri.xs = x * g.sx;
-    ri.off = ((n * g.Hi + ri.ys) * g.Wi + ri.xs) * g.a_pitch;
-    return ri;
+    return make_row(g, r, n, y, rem - y * g.Wg);
 }
 
 __device__ __forceinline__ int out_pixel(const ConvGeom& g, int r) {
@@ -73,20 +101,24 @@ __device__ __forceinline__ float4 load_a(const ConvGeom& g, const float* __restr
                                          int q, bool* ok) {
     const int dy = g.dy[t], dx = g.dx[t];
     const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[t];
-    *ok = ri.valid & ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
+    *ok = ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
     const int off = *ok ? ri.off + delta : 0;
     return *reinterpret_cast<const float4*>(A + off + 4 * q);
 }
 
 // previous layer's BatchNorm + ReLU folded into the operand load; padding stays exactly zero
-__device__ __forceinline__ float4 transform_a(float4 v, bool ok, bool has_t, const float4& sc, const float4& sh) {
-    if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has_t) {
+template <bool HAS_T>
+__device__ __forceinline__ float4 transform_a(float4 v, bool ok, const float4& sc, const float4& sh) {
+    if (HAS_T) {
         v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
         v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
         v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
         v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
     }
+    v.x = ok ? v.x : 0.f;
+    v.y = ok ? v.y : 0.f;
+    v.z = ok ? v.z : 0.f;
+    v.w = ok ? v.w : 0.f;
     return v;
 }
 
@@ -98,8 +130,10 @@ __device__ __forceinline__ float apply_act(float v) {
 }
 
 // ---------------------------------------------------------------------------- forward gather-GEMM
-template <int ACT>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGeom g, const float* __restrict__ A,
+// One software pipeline over the block's (tile, tap) steps: while the MFMAs of step s run out of LDS, the
+// operands of step s+1 (possibly the first tap of the block's next tile) are already in flight to registers.
+template <int ACT, bool HAS_T>
+__global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const float* __restrict__ A,
                                                            const float* __restrict__ Wt,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ a_scale,
@@ -107,86 +141,118 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGeom g, const flo
                                                            float* __restrict__ out, float* __restrict__ stats_part) {
     __shared__ __align__(16) float As[BM * LDA];
     __shared__ __align__(16) float Ws[64 * LDA];
-    __shared__ int opix[BM];
+    __shared__ int opix[2][BM];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int q = tid & 15, rb = tid >> 4;
     const int nb = blockIdx.y;
-    const float* Wn = Wt + nb * g.w_nblk_stride;
-    const bool has_t = a_scale != nullptr;
+    const float* Wn = Wt + nb * g.w_nblk_stride + (long)rb * g.w_pitch + 4 * q;
+    const long w16 = 16L * g.w_pitch;
     const int ntiles = (g.rows_total + BM - 1) / BM;
+    const int nsteps = ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * g.ntaps;
+    const RowDecoder dec(g);
     float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
     const float b0 = bias ? bias[nb * 64 + i] : 0.f;
     const float b1 = bias ? bias[nb * 64 + 32 + i] : 0.f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        RowInfo ri[8];
+    RowInfo ri[8];
+    float4 ra[8], rw0, rw1, rw2, rw3;
+    bool ok[8];
+    int ltile = blockIdx.x;          // tile whose operands are being loaded
+    int par = 0;                     // opix buffer of the tile being multiplied
+    dec.decode<8>(ltile * BM + rb, 16, [&](int e, int n, int y, int x) {
+        ri[e] = make_row(g, ltile * BM + rb + 16 * e, n, y, x);
+    });
+    if (tid < BM) opix[0][tid] = out_pixel(g, ltile * BM + tid);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ri[e] = row_info(g, tile * BM + rb + 16 * e);
-        if (tid < BM) opix[tid] = out_pixel(g, tile * BM + tid);
-        floatx16 acc0 = {}, acc1 = {};
-        float4 ra[8], rw[4];
-        bool ok[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], 0, q, &ok[e]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            rw[e] = *reinterpret_cast<const float4*>(Wn + (long)(rb + 16 * e) * g.w_pitch + 4 * q);
-        for (int t = 0; t < g.ntaps; ++t) {
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has_t) {
-                sc = *reinterpret_cast<const float4*>(a_scale + g.a_col[t] + 4 * q);
-                sh = *reinterpret_cast<const float4*>(a_shift + g.a_col[t] + 4 * q);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<float4*>(&As[(rb + 16 * e) * LDA + 4 * q]) =
-                    transform_a(ra[e], ok[e], has_t, sc, sh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(&Ws[(rb + 16 * e) * LDA + 4 * q]) = rw[e];
-            __syncthreads();
-            if (t + 1 < g.ntaps) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], t + 1, q, &ok[e]);
-                const float* Wn1 = Wn + (t + 1) * g.w_tap_stride;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    rw[e] = *reinterpret_cast<const float4*>(Wn1 + (long)(rb + 16 * e) * g.w_pitch + 4 * q);
-            }
-            const float* ap = &As[(32 * w + i) * LDA + 4 * h];
-            const float* bp0 = &Ws[i * LDA + 4 * h];
-            const float* bp1 = &Ws[(32 + i) * LDA + 4 * h];
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * kk);
-                const float4 p4 = *reinterpret_cast<const float4*>(bp0 + 8 * kk);
-                const float4 r4 = *reinterpret_cast<const float4*>(bp1 + 8 * kk);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, p4.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, r4.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, p4.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, r4.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, p4.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, r4.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, p4.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
-            }
+    for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], 0, q, &ok[e]);
+    rw0 = *reinterpret_cast<const float4*>(Wn);
+    rw1 = *reinterpret_cast<const float4*>(Wn + w16);
+    rw2 = *reinterpret_cast<const float4*>(Wn + 2 * w16);
+    rw3 = *reinterpret_cast<const float4*>(Wn + 3 * w16);
+
+    floatx16 acc0 = {}, acc1 = {};
+    int t = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (HAS_T) {
+            sc = *reinterpret_cast<const float4*>(a_scale + g.a_col[t] + 4 * q);
+            sh = *reinterpret_cast<const float4*>(a_shift + g.a_col[t] + 4 * q);
         }
-        // epilogue: C[row = (reg&3) + 8*(reg>>2) + 4*h][col = i]
+        __syncthreads();
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const int op = opix[row];
-            if (op >= 0) {
-                const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
-                ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
-                ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
-                float* o = out + (long)op * g.o_pitch + nb * 64;
-                o[i] = apply_act<ACT>(v0);
-                o[32 + i] = apply_act<ACT>(v1);
-            }
+        for (int e = 0; e < 8; ++e)
+            *reinterpret_cast<float4*>(&As[(rb + 16 * e) * LDA + 4 * q]) = transform_a<HAS_T>(ra[e], ok[e], sc, sh);
+        *reinterpret_cast<float4*>(&Ws[rb * LDA + 4 * q]) = rw0;
+        *reinterpret_cast<float4*>(&Ws[(rb + 16) * LDA + 4 * q]) = rw1;
+        *reinterpret_cast<float4*>(&Ws[(rb + 32) * LDA + 4 * q]) = rw2;
+        *reinterpret_cast<float4*>(&Ws[(rb + 48) * LDA + 4 * q]) = rw3;
+        __syncthreads();
+        // operands of the next step (past the block's last step the rows are all invalid: element 0 is read)
+        int tn = t + 1;
+        if (tn == g.ntaps) {
+            tn = 0;
+            ltile += gridDim.x;
+            dec.decode<8>(ltile * BM + rb, 16, [&](int e, int n, int y, int x) {
+                ri[e] = make_row(g, ltile * BM + rb + 16 * e, n, y, x);
+            });
+            if (tid < BM) opix[par ^ 1][tid] = out_pixel(g, ltile * BM + tid);
         }
-        __syncthreads();     // opix reused by the next tile
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tn, q, &ok[e]);
+        {
+            const float* Wn1 = Wn + tn * g.w_tap_stride;
+            rw0 = *reinterpret_cast<const float4*>(Wn1);
+            rw1 = *reinterpret_cast<const float4*>(Wn1 + w16);
+            rw2 = *reinterpret_cast<const float4*>(Wn1 + 2 * w16);
+            rw3 = *reinterpret_cast<const float4*>(Wn1 + 3 * w16);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs that hide it
+        const float* ap = &As[(32 * w + i) * LDA + 4 * h];
+        const float* bp0 = &Ws[i * LDA + 4 * h];
+        const float* bp1 = &Ws[(32 + i) * LDA + 4 * h];
+        float4 a4 = *reinterpret_cast<const float4*>(ap);
+        float4 p4 = *reinterpret_cast<const float4*>(bp0);
+        float4 r4 = *reinterpret_cast<const float4*>(bp1);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float4 an = a4, pn = p4, rn = r4;
+            if (kk < 7) {        // fragments of the next k-slice are read while this slice multiplies
+                an = *reinterpret_cast<const float4*>(ap + 8 * kk + 8);
+                pn = *reinterpret_cast<const float4*>(bp0 + 8 * kk + 8);
+                rn = *reinterpret_cast<const float4*>(bp1 + 8 * kk + 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, p4.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, r4.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, p4.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, r4.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, p4.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, r4.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, p4.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
+            a4 = an; p4 = pn; r4 = rn;
+        }
+        if (tn == 0) {
+            // epilogue of the finished tile: C[row = (reg&3) + 8*(reg>>2) + 4*h][col = i]
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int op = opix[par][row];
+                if (op >= 0) {
+                    const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
+                    ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
+                    ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
+                    float* o = out + (long)op * g.o_pitch + nb * 64;
+                    o[i] = apply_act<ACT>(v0);
+                    o[32 + i] = apply_act<ACT>(v1);
+                }
+            }
+            acc0 = floatx16{};
+            acc1 = floatx16{};
+            par ^= 1;
+        }
+        t = tn;
     }
     if (stats_part) {
         ssum0 += __shfl_xor(ssum0, 32); ssum1 += __shfl_xor(ssum1, 32);
@@ -254,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 *reinterpret_cast<float4*>(&As[(rb + 16 * e) * 64 + 4 * q]) =
-                    transform_a(ra[e], ok[e], has_t, sc, sh);
+                    (has_t ? transform_a<true>(ra[e], ok[e], sc, sh) : transform_a<false>(ra[e], ok[e], sc, sh));
             __syncthreads();
             if (t + 1 < NT) {
 #pragma unroll
@@ -335,6 +401,7 @@ static int check_geom(const ConvGeom& g) {
     CMVAE_REQUIRE(g.rows_total >= 0 && g.Hg > 0 && g.Wg > 0 && g.Hi > 0 && g.Wi > 0 && g.Ho > 0 && g.Wo > 0,
                   "conv geometry: non-positive extent");
     CMVAE_REQUIRE(g.ntaps >= 1 && g.ntaps <= 16, "conv geometry: ntaps=%d outside [1,16]", g.ntaps);
+    CMVAE_REQUIRE((long)g.Hg * g.Wg <= (1L << 20), "conv geometry: per-image grid larger than 2^20 rows");
     CMVAE_REQUIRE(g.a_pitch >= 64 && g.a_pitch % 4 == 0 && g.o_pitch >= 64, "conv geometry: bad pitch");
     CMVAE_REQUIRE(g.rows_total % (g.Hg * g.Wg) == 0, "conv geometry: rows not a multiple of the per-image grid");
     CMVAE_REQUIRE((g.Hg - 1) * g.oys + g.oy0 < g.Ho && (g.Wg - 1) * g.oxs + g.ox0 < g.Wo && g.oy0 >= 0 && g.ox0 >= 0,
@@ -363,9 +430,15 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
 
 static int gemm_grid(int rows_total, int nblk_cols) {
     const int ntiles = (rows_total + BM - 1) / BM;
-    int gx = 512 / (nblk_cols > 0 ? nblk_cols : 1);
+    int gx = 768 / (nblk_cols > 0 ? nblk_cols : 1);
     if (gx < 64) gx = 64;
     return ntiles < gx ? (ntiles > 0 ? ntiles : 1) : gx;
+}
+
+// weight-gradient blocks: two per CU (64 KB of LDS each), every block leaves one partial per tap
+static int wgrad_grid(int rows_total) {
+    const int ntiles = (rows_total + BM - 1) / BM;
+    return ntiles < 512 ? (ntiles > 0 ? ntiles : 1) : 512;
 }
 
 extern "C" int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks) { return gemm_grid(rows_total, n_col_blocks); }
@@ -383,16 +456,24 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     if (g.rows_total == 0) return 0;
     dim3 grid(gemm_grid(g.rows_total, n_col_blocks), n_col_blocks);
     hipStream_t st = (hipStream_t)stream;
+#define CMVAE_LAUNCH_GEMM(ACT)                                                                                  \
+    if (a_scale)                                                                                                \
+        hipLaunchKernelGGL((conv_gemm_kernel<ACT, true>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale,      \
+                           a_shift, out, stats_part);                                                           \
+    else                                                                                                        \
+        hipLaunchKernelGGL((conv_gemm_kernel<ACT, false>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale,     \
+                           a_shift, out, stats_part)
     switch (act) {
-        case 0: hipLaunchKernelGGL(conv_gemm_kernel<0>, grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part); break;
-        case 1: hipLaunchKernelGGL(conv_gemm_kernel<1>, grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part); break;
-        default: hipLaunchKernelGGL(conv_gemm_kernel<2>, grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part); break;
+        case 0: CMVAE_LAUNCH_GEMM(0); break;
+        case 1: CMVAE_LAUNCH_GEMM(1); break;
+        default: CMVAE_LAUNCH_GEMM(2); break;
     }
+#undef CMVAE_LAUNCH_GEMM
     return check_launch("conv_gemm_kernel");
 }
 
 extern "C" size_t cmvae_conv_wgrad_workspace_bytes(int rows_total) {
-    const int nblk = gemm_grid(rows_total, 2);
+    const int nblk = wgrad_grid(rows_total);
     return align_up((size_t)nblk * 4 * 4096 * sizeof(float)) + align_up((size_t)nblk * 64 * sizeof(float));
 }
 
@@ -408,7 +489,7 @@ extern "C" int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, con
                   "cmvae_conv_wgrad: bad gradient pitch/column");
     CMVAE_REQUIRE(workspace_bytes >= cmvae_conv_wgrad_workspace_bytes(g.rows_total), "cmvae_conv_wgrad: workspace too small");
     if (g.rows_total == 0) return 0;
-    const int nblk = gemm_grid(g.rows_total, 2);
+    const int nblk = wgrad_grid(g.rows_total);
     float* part = (float*)workspace;
     float* db_part = (float*)((char*)workspace + align_up((size_t)nblk * 4 * 4096 * sizeof(float)));
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,35 @@
+"""Host enqueue time vs device time of one training step (is the step launch-bound?)."""
+import sys, time, cProfile, pstats, io
+import numpy as np, torch
+sys.path.insert(0, '.')
+import bench
+from cmvae_amd import dist as cdist
+dev = torch.device('cuda:0')
+model = bench.build_model(dev)
+flat = cdist.FlatGrads(model.parameters())
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+np.random.seed(1); torch.manual_seed(1)
+X = bench.synth_images(bench.B_PER_GPU, bench.SAMPLE, 'cpu', 100).to(dev)
+N = bench.SAMPLE * bench.MC
+
+def step():
+    model.train(); flat.zero()
+    idx = torch.from_numpy(cdist.draw_em_init(N, bench.WAY, bench.B_PER_GPU, 0, 1)).to(dev)
+    _, rec, kl, h, _ = model(X, 0.1, 0.1, 1e-4, init_idx=idx)
+    (rec + kl + h).backward()
+    flat.allreduce(); opt.step()
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+hs, ts = [], []
+for _ in range(10):
+    t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    hs.append(t1 - t0); ts.append(t2 - t0)
+print('host enqueue ms %.2f   total ms %.2f' % (1e3 * np.median(hs), 1e3 * np.median(ts)))
+if len(sys.argv) > 1:
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize(); pr.disable()
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(35); print(s.getvalue()[:6000])
