@@ -171,10 +171,8 @@ def main():
 
     model = build_model(device)
     flat = cdist.FlatGrads(model.parameters())
-    try:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
-    except Exception:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+    from cmvae_amd.linear import FlatAdam
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)          # Adam as in omniglot/trainer.py:48-52
     np.random.seed(10086)
     torch.manual_seed(10086 + rank)
 

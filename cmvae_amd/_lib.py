@@ -28,7 +28,7 @@ class ConvGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('rows_total', 'Hg', 'Wg', 'Hi', 'Wi', 'sy', 'sx', 'Ho', 'Wo', 'oys',
                                               'oxs', 'oy0', 'ox0', 'ntaps', 'a_pitch', 'o_pitch', 'w_pitch')] + \
                [('w_tap_stride', ctypes.c_int64), ('w_nblk_stride', ctypes.c_int64),
-                ('dy', ctypes.c_int32 * 16), ('dx', ctypes.c_int32 * 16), ('a_col', ctypes.c_int32 * 16)]
+                ('dy', ctypes.c_int32 * 32), ('dx', ctypes.c_int32 * 32), ('a_col', ctypes.c_int32 * 32)]
 
 
 _PG = ctypes.POINTER(ConvGeom)
@@ -86,6 +86,18 @@ SIGNATURES = {
     'cmvae_conv_wgrad': (c_int, [_PG, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  ctypes.POINTER(c_int64), c_int64, c_int64, c_void_p, c_void_p, c_int,
                                  c_void_p, c_size_t, c_void_p]),
+    'cmvae_linear_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                 c_void_p]),
+    'cmvae_act_bwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    'cmvae_linear_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'cmvae_linear_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'cmvae_causal_lc_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'cmvae_causal_lc_bwd_grid': (c_int, [c_int]),
+    'cmvae_causal_lc_bwd_partial_len': (c_int, []),
+    'cmvae_causal_lc_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'cmvae_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float,
+                                c_float, c_float, c_void_p]),
 }
 
 

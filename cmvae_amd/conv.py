@@ -72,8 +72,8 @@ def geom_convT_dgrad(n, Hi, Wi, k, C=64):
 
 
 def geom_linear(rows, K, N, a_pitch=None, o_pitch=None):
-    """y = x @ W^T with W [N,K] (torch layout); K, N multiples of 64, K <= 1024."""
-    assert K % 64 == 0 and N % 64 == 0 and K // 64 <= 16
+    """y = x @ W^T with W [N,K] (torch layout); K, N multiples of 64, K <= 2048."""
+    assert K % 64 == 0 and N % 64 == 0 and K // 64 <= 32
     taps = [(0, 0)] * (K // 64)
     return _geom(rows, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, taps, a_pitch or K, o_pitch or N, K, 64, 64 * K,
                  a_cols=[64 * t for t in range(K // 64)])

@@ -32,8 +32,8 @@ struct ConvGeom {
     int w_pitch;              // floats between consecutive output columns of W_t ([col][k] layout)
     long w_tap_stride;        // floats between taps
     long w_nblk_stride;       // floats between 64-column output blocks (blockIdx.y)
-    int dy[16], dx[16];       // dword arrays: indexed by the (uniform) tap counter they stay in SGPRs
-    int a_col[16];
+    int dy[32], dx[32];       // dword arrays: indexed by the (uniform) tap counter they stay in SGPRs
+    int a_col[32];
 };
 
 struct RowInfo {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static int check_geom(const ConvGeom& g) {
     CMVAE_REQUIRE(g.rows_total >= 0 && g.Hg > 0 && g.Wg > 0 && g.Hi > 0 && g.Wi > 0 && g.Ho > 0 && g.Wo > 0,
                   "conv geometry: non-positive extent");
-    CMVAE_REQUIRE(g.ntaps >= 1 && g.ntaps <= 16, "conv geometry: ntaps=%d outside [1,16]", g.ntaps);
+    CMVAE_REQUIRE(g.ntaps >= 1 && g.ntaps <= 32, "conv geometry: ntaps=%d outside [1,32]", g.ntaps);
     CMVAE_REQUIRE((long)g.Hg * g.Wg <= (1L << 20), "conv geometry: per-image grid larger than 2^20 rows");
     CMVAE_REQUIRE(g.a_pitch >= 64 && g.a_pitch % 4 == 0 && g.o_pitch >= 64, "conv geometry: bad pitch");
     CMVAE_REQUIRE(g.rows_total % (g.Hg * g.Wg) == 0, "conv geometry: rows not a multiple of the per-image grid");
@@ -424,7 +424,7 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
     g.Ho = c->Ho; g.Wo = c->Wo; g.oys = c->oys; g.oxs = c->oxs; g.oy0 = c->oy0; g.ox0 = c->ox0; g.ntaps = c->ntaps;
     g.a_pitch = c->a_pitch; g.o_pitch = c->o_pitch; g.w_pitch = c->w_pitch; g.w_tap_stride = c->w_tap_stride;
     g.w_nblk_stride = c->w_nblk_stride;
-    for (int t = 0; t < 16; ++t) { g.dy[t] = c->dy[t]; g.dx[t] = c->dx[t]; g.a_col[t] = c->a_col[t]; }
+    for (int t = 0; t < 32; ++t) { g.dy[t] = c->dy[t]; g.dx[t] = c->dx[t]; g.a_col[t] = c->a_col[t]; }
     return g;
 }
 
@@ -477,22 +477,12 @@ extern "C" size_t cmvae_conv_wgrad_workspace_bytes(int rows_total) {
     return align_up((size_t)nblk * 4 * 4096 * sizeof(float)) + align_up((size_t)nblk * 64 * sizeof(float));
 }
 
-extern "C" int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, const float* a_scale,
-                                const float* a_shift, const float* G, int g_pitch, int g_col,
-                                const int64_t* tap_off_host, int64_t s_ci, int64_t s_co, float* dW, float* db,
-                                int accumulate_db, void* workspace, size_t workspace_bytes, void* stream) {
-    CMVAE_REQUIRE(geom && A && G && tap_off_host && dW && workspace, "cmvae_conv_wgrad: NULL argument");
-    CMVAE_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "cmvae_conv_wgrad: scale and shift go together");
-    ConvGeom g = to_geom(geom);
-    if (int e = check_geom(g)) return e;
-    CMVAE_REQUIRE(g_pitch >= 64 && g_col >= 0 && g_col + 64 <= g_pitch && g_pitch % 4 == 0 && g_col % 4 == 0,
-                  "cmvae_conv_wgrad: bad gradient pitch/column");
-    CMVAE_REQUIRE(workspace_bytes >= cmvae_conv_wgrad_workspace_bytes(g.rows_total), "cmvae_conv_wgrad: workspace too small");
-    if (g.rows_total == 0) return 0;
+static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale, const float* a_shift,
+                        const float* G, int g_pitch, int g_col, const int64_t* tap_off_host, int64_t s_ci,
+                        int64_t s_co, float* dW, float* db, int accumulate_db, void* workspace, hipStream_t st) {
     const int nblk = wgrad_grid(g.rows_total);
     float* part = (float*)workspace;
     float* db_part = (float*)((char*)workspace + align_up((size_t)nblk * 4 * 4096 * sizeof(float)));
-    hipStream_t st = (hipStream_t)stream;
     for (int t0 = 0; t0 < g.ntaps; t0 += 4) {
         const int nt = g.ntaps - t0 < 4 ? g.ntaps - t0 : 4;
         float* dbp = (db && t0 == 0) ? db_part : nullptr;
@@ -509,6 +499,167 @@ extern "C" int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, con
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nt * 64 + (dbp ? 1 : 0)), dim3(256), 0, st, part, nblk, nt, o, dW,
                            dbp, dbp ? db : nullptr, accumulate_db);
         if (int e = check_launch("wgrad_reduce_kernel")) return e;
+    }
+    return 0;
+}
+
+extern "C" int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, const float* a_scale,
+                                const float* a_shift, const float* G, int g_pitch, int g_col,
+                                const int64_t* tap_off_host, int64_t s_ci, int64_t s_co, float* dW, float* db,
+                                int accumulate_db, void* workspace, size_t workspace_bytes, void* stream) {
+    CMVAE_REQUIRE(geom && A && G && tap_off_host && dW && workspace, "cmvae_conv_wgrad: NULL argument");
+    CMVAE_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "cmvae_conv_wgrad: scale and shift go together");
+    ConvGeom g = to_geom(geom);
+    if (int e = check_geom(g)) return e;
+    CMVAE_REQUIRE(g_pitch >= 64 && g_col >= 0 && g_col + 64 <= g_pitch && g_pitch % 4 == 0 && g_col % 4 == 0,
+                  "cmvae_conv_wgrad: bad gradient pitch/column");
+    CMVAE_REQUIRE(workspace_bytes >= cmvae_conv_wgrad_workspace_bytes(g.rows_total), "cmvae_conv_wgrad: workspace too small");
+    if (g.rows_total == 0) return 0;
+    return wgrad_launch(g, A, a_scale, a_shift, G, g_pitch, g_col, tap_off_host, s_ci, s_co, dW, db, accumulate_db,
+                        workspace, (hipStream_t)stream);
+}
+
+// ============================================================================ nn.Linear on the same kernels
+// y = act(x W^T + b): one "image" per row, in_f/64 taps over the operand columns, out_f/64 column blocks.
+namespace cmvae {
+
+static ConvGeom linear_geom(int rows, int K, int N, int a_pitch, int o_pitch) {
+    ConvGeom g{};
+    g.rows_total = rows;
+    g.Hg = g.Wg = g.Hi = g.Wi = g.sy = g.sx = g.Ho = g.Wo = g.oys = g.oxs = 1;
+    g.ntaps = K / 64;
+    g.a_pitch = a_pitch; g.o_pitch = o_pitch; g.w_pitch = K;
+    g.w_tap_stride = 64; g.w_nblk_stride = 64L * K;
+    for (int t = 0; t < g.ntaps; ++t) g.a_col[t] = 64 * t;
+    return g;
+}
+
+static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const float* bias, int act, int ncb,
+                       float* out, hipStream_t st) {
+    dim3 grid(gemm_grid(g.rows_total, ncb), ncb);
+    const float* nul = nullptr;
+    float* nostats = nullptr;
+    switch (act) {
+        case 0: hipLaunchKernelGGL((conv_gemm_kernel<0, false>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
+        case 1: hipLaunchKernelGGL((conv_gemm_kernel<1, false>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
+        default: hipLaunchKernelGGL((conv_gemm_kernel<2, false>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
+    }
+    return check_launch("conv_gemm_kernel (linear)");
+}
+
+// Wt2[i][o] = W[o][i]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ W, int out_f, int in_f,
+                                                        float* __restrict__ Wt2) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = W[(long)(o0 + r) * in_f + i0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) Wt2[(long)(i0 + r) * out_f + o0 + tx] = tile[tx][r];
+}
+
+// column sums of x [rows, cols] in two fixed-order stages: part[blk][cols], then out[cols]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int cols,
+                                                             int pitch, float* __restrict__ part) {
+    const int rpb = (rows + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float s0 = 0.f, s1 = 0.f;
+        int r = r0;
+        for (; r + 1 < r1; r += 2) {
+            s0 += x[(long)r * pitch + c];
+            s1 += x[(long)(r + 1) * pitch + c];
+        }
+        if (r < r1) s0 += x[(long)r * pitch + c];
+        part[(long)blockIdx.x * cols + c] = s0 + s1;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols,
+                                                           float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * cols + c];
+    out[c] = s;
+}
+
+constexpr int COLSUM_BLOCKS = 256;
+
+}  // namespace cmvae
+
+static int check_linear(const char* who, int rows, int in_f, int out_f) {
+    CMVAE_REQUIRE(rows >= 0 && in_f >= 64 && out_f >= 64 && in_f % 64 == 0 && out_f % 64 == 0 && in_f <= 2048 &&
+                  out_f <= 2048, "%s: rows=%d in=%d out=%d (features must be multiples of 64, at most 2048)", who,
+                  rows, in_f, out_f);
+    return 0;
+}
+
+extern "C" int cmvae_linear_fwd(const float* X, int x_pitch, int rows, int in_f, int out_f, const float* W,
+                                const float* bias, int act, float* Y, int y_pitch, void* stream) {
+    CMVAE_REQUIRE(X && W && Y, "cmvae_linear_fwd: NULL argument");
+    if (int e = check_linear("cmvae_linear_fwd", rows, in_f, out_f)) return e;
+    CMVAE_REQUIRE(x_pitch >= in_f && x_pitch % 4 == 0 && y_pitch >= out_f && act >= 0 && act <= 2,
+                  "cmvae_linear_fwd: bad pitch / act");
+    CMVAE_REQUIRE((long)rows * x_pitch < (1L << 31), "cmvae_linear_fwd: operand larger than 2^31 elements");
+    if (rows == 0) return 0;
+    return launch_gemm(linear_geom(rows, in_f, out_f, x_pitch, y_pitch), X, W, bias, act, out_f / 64, Y,
+                       (hipStream_t)stream);
+}
+
+extern "C" size_t cmvae_linear_bwd_workspace_bytes(int rows, int in_f, int out_f) {
+    return cmvae_conv_wgrad_workspace_bytes(rows) + align_up((size_t)in_f * out_f * sizeof(float)) +
+           align_up((size_t)COLSUM_BLOCKS * out_f * sizeof(float));
+}
+
+extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, const float* dZ, int dz_pitch, int rows,
+                                int in_f, int out_f, float* dX, int dx_pitch, float* dW, float* db, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    CMVAE_REQUIRE(X && W && dZ && dW && workspace, "cmvae_linear_bwd: NULL argument");
+    if (int e = check_linear("cmvae_linear_bwd", rows, in_f, out_f)) return e;
+    CMVAE_REQUIRE(x_pitch >= in_f && x_pitch % 4 == 0 && dz_pitch >= out_f && dz_pitch % 4 == 0 &&
+                  (!dX || dx_pitch >= in_f), "cmvae_linear_bwd: bad pitch");
+    CMVAE_REQUIRE((long)rows * x_pitch < (1L << 31) && (long)rows * dz_pitch < (1L << 31),
+                  "cmvae_linear_bwd: operand larger than 2^31 elements");
+    CMVAE_REQUIRE(workspace_bytes >= cmvae_linear_bwd_workspace_bytes(rows, in_f, out_f),
+                  "cmvae_linear_bwd: workspace too small");
+    CMVAE_REQUIRE(rows >= 1, "cmvae_linear_bwd: no rows");
+    hipStream_t st = (hipStream_t)stream;
+    char* wsb = (char*)workspace;
+    void* wg_ws = wsb;
+    float* Wt2 = (float*)(wsb + cmvae_conv_wgrad_workspace_bytes(rows));
+    float* cs_part = (float*)((char*)Wt2 + align_up((size_t)in_f * out_f * sizeof(float)));
+    const int kin = in_f / 64, kout = out_f / 64;
+    if (dX) {       // dX = dZ @ W: contraction over the out_f columns of dZ, weights transposed to [in][out]
+        hipLaunchKernelGGL(transpose_kernel, dim3(in_f / 32, out_f / 32), dim3(256), 0, st, W, out_f, in_f, Wt2);
+        if (int e = check_launch("transpose_kernel")) return e;
+        if (int e = launch_gemm(linear_geom(rows, out_f, in_f, dz_pitch, dx_pitch), dZ, Wt2, nullptr, 0, kin, dX, st))
+            return e;
+    }
+    // dW[o][i] = sum_r dZ[r][o] X[r][i]: the operand with more 64-column blocks supplies the taps (4 per launch)
+    int64_t tap_off[32];
+    if (kout * ((kin + 3) / 4) <= kin * ((kout + 3) / 4)) {
+        const ConvGeom g = linear_geom(rows, in_f, 64, x_pitch, 64);
+        for (int cb = 0; cb < kout; ++cb) {
+            for (int t = 0; t < kin; ++t) tap_off[t] = 64L * cb * in_f + 64 * t;
+            if (int e = wgrad_launch(g, X, nullptr, nullptr, dZ, dz_pitch, 64 * cb, tap_off, 1, in_f, dW,
+                                     db ? db + 64 * cb : nullptr, 0, wg_ws, st))
+                return e;
+        }
+    } else {
+        const ConvGeom g = linear_geom(rows, out_f, 64, dz_pitch, 64);
+        for (int cb = 0; cb < kin; ++cb) {
+            for (int t = 0; t < kout; ++t) tap_off[t] = 64L * t * in_f + 64 * cb;
+            if (int e = wgrad_launch(g, dZ, nullptr, nullptr, X, x_pitch, 64 * cb, tap_off, in_f, 1, dW, nullptr, 0,
+                                     wg_ws, st))
+                return e;
+        }
+        if (db) {
+            const int nb = rows < COLSUM_BLOCKS ? rows : COLSUM_BLOCKS;
+            hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, dZ, rows, out_f, dz_pitch, cs_part);
+            if (int e = check_launch("colsum_partial_kernel")) return e;
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((out_f + 255) / 256), dim3(256), 0, st, cs_part, nb, out_f, db);
+            if (int e = check_launch("colsum_final_kernel")) return e;
+        }
     }
     return 0;
 }

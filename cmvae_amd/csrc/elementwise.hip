@@ -188,3 +188,151 @@ extern "C" int cmvae_expm_trace(const float* A, float* h, float* grad, void* str
     hipLaunchKernelGGL(expm_trace_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, h, grad);
     return check_launch("expm_trace_kernel");
 }
+
+// ============================================================================ Linear-layer helpers
+namespace cmvae {
+
+// dZ = dY * act'(pre-activation), from the saved post-activation Y (ReLU: y > 0; ELU: y > 0 ? 1 : y + 1)
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__ dY, const float4* __restrict__ Y,
+                                                      long n4, float4* __restrict__ dZ) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const float4 g = dY[e], y = Y[e];
+        float4 o;
+        if (ACT == 1) {
+            o.x = y.x > 0.f ? g.x : 0.f; o.y = y.y > 0.f ? g.y : 0.f;
+            o.z = y.z > 0.f ? g.z : 0.f; o.w = y.w > 0.f ? g.w : 0.f;
+        } else {
+            o.x = y.x > 0.f ? g.x : g.x * (y.x + 1.f); o.y = y.y > 0.f ? g.y : g.y * (y.y + 1.f);
+            o.z = y.z > 0.f ? g.z : g.z * (y.z + 1.f); o.w = y.w > 0.f ? g.w : g.w * (y.w + 1.f);
+        }
+        dZ[e] = o;
+    }
+}
+
+// ---------------------------------------------------------------- NOTEARS-MLP tail on bulk rows
+// eps[r][j] = x[r][j] - (sum_m hid[r][32j+m] * w2[j][m] + b2[j]),  hid = elu(fc1(x)) from the Linear kernel.
+// 8 lanes x float4 cover the 32 hidden units of one (row, j).
+__global__ __launch_bounds__(256) void causal_lc_fwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ hid,
+                                                            const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, long items,
+                                                            float* __restrict__ eps) {
+    const int l8 = threadIdx.x & 7;
+    for (long it = (long)blockIdx.x * 32 + (threadIdx.x >> 3); it < items; it += (long)gridDim.x * 32) {
+        const int j = (int)(it & 63);
+        const float4 h = *reinterpret_cast<const float4*>(hid + it * M1 + 4 * l8);
+        const float4 w = *reinterpret_cast<const float4*>(w2 + j * M1 + 4 * l8);
+        float s = fmaf(h.x, w.x, fmaf(h.y, w.y, fmaf(h.z, w.z, h.w * w.w)));
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (l8 == 0) eps[it] = x[it] - (s + b2[j]);
+    }
+}
+
+// backward of the tail: g = -d_eps[r][j];  d_pre[r][32j+m] = g * w2[j][m] * elu'(.);  per-block partials of
+// dw2[j][m] = sum_r g * hid[r][32j+m] and db2[j] = sum_r g.  512 threads = one float4 of every hidden column.
+constexpr int LC_BWD_L = HID + D;
+__global__ __launch_bounds__(512) void causal_lc_bwd_kernel(const float* __restrict__ d_eps,
+                                                            const float* __restrict__ hid,
+                                                            const float* __restrict__ w2, int rows,
+                                                            float* __restrict__ d_pre, float* __restrict__ part) {
+    const int t = threadIdx.x, j = t >> 3;
+    const float4 w = *reinterpret_cast<const float4*>(w2 + 4 * t);
+    float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float db = 0.f;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float g = -d_eps[(long)r * D + j];
+        const float4 h = *reinterpret_cast<const float4*>(hid + (long)r * HID + 4 * t);
+        float4 o;
+        o.x = g * w.x * (h.x > 0.f ? 1.f : h.x + 1.f);
+        o.y = g * w.y * (h.y > 0.f ? 1.f : h.y + 1.f);
+        o.z = g * w.z * (h.z > 0.f ? 1.f : h.z + 1.f);
+        o.w = g * w.w * (h.w > 0.f ? 1.f : h.w + 1.f);
+        *reinterpret_cast<float4*>(d_pre + (long)r * HID + 4 * t) = o;
+        dw.x = fmaf(g, h.x, dw.x); dw.y = fmaf(g, h.y, dw.y);
+        dw.z = fmaf(g, h.z, dw.z); dw.w = fmaf(g, h.w, dw.w);
+        db += g;
+    }
+    float* pb = part + (long)blockIdx.x * LC_BWD_L;
+    *reinterpret_cast<float4*>(pb + 4 * t) = dw;
+    if ((t & 7) == 0) pb[HID + j] = db;
+}
+
+// ---------------------------------------------------------------- Adam with L2 weight decay (torch.optim.Adam)
+// g' = g + wd*p; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                   float4* __restrict__ m, float4* __restrict__ v, long n4, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1,
+                                                   float bc2_sqrt) {
+    const float step = lr / bc1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        float4 pp = p[e], gg = g[e], mm = m[e], vv = v[e];
+#define CMVAE_ADAM1(c)                                                   \
+        {                                                                \
+            const float gr = fmaf(wd, pp.c, gg.c);                       \
+            mm.c = fmaf(b1, mm.c, (1.f - b1) * gr);                      \
+            vv.c = fmaf(b2, vv.c, (1.f - b2) * gr * gr);                 \
+            pp.c -= step * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));      \
+        }
+        CMVAE_ADAM1(x) CMVAE_ADAM1(y) CMVAE_ADAM1(z) CMVAE_ADAM1(w)
+#undef CMVAE_ADAM1
+        p[e] = pp; m[e] = mm; v[e] = vv;
+    }
+}
+
+static int grid_for(long n, int per_block) {
+    long b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace cmvae
+
+extern "C" int cmvae_act_bwd(const float* dY, const float* Y, int64_t n, int act, float* dZ, void* stream) {
+    CMVAE_REQUIRE(dY && Y && dZ && n >= 0 && n % 4 == 0 && (act == 1 || act == 2), "cmvae_act_bwd: bad arguments");
+    if (n == 0) return 0;
+    const long n4 = n / 4;
+    if (act == 1)
+        hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(grid_for(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)dY, (const float4*)Y, n4, (float4*)dZ);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<2>, dim3(grid_for(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)dY, (const float4*)Y, n4, (float4*)dZ);
+    return check_launch("act_bwd_kernel");
+}
+
+extern "C" int cmvae_causal_lc_fwd(const float* x, const float* hid, const float* w2, const float* b2, int rows,
+                                   float* eps, void* stream) {
+    CMVAE_REQUIRE(x && hid && w2 && b2 && eps && rows >= 0, "cmvae_causal_lc_fwd: bad arguments");
+    if (rows == 0) return 0;
+    const long items = (long)rows * D;
+    hipLaunchKernelGGL(causal_lc_fwd_kernel, dim3(grid_for(items, 32)), dim3(256), 0, (hipStream_t)stream, x, hid, w2,
+                       b2, items, eps);
+    return check_launch("causal_lc_fwd_kernel");
+}
+
+extern "C" int cmvae_causal_lc_bwd_grid(int rows) { return rows < 1024 ? (rows > 0 ? rows : 1) : 1024; }
+extern "C" int cmvae_causal_lc_bwd_partial_len(void) { return LC_BWD_L; }
+
+extern "C" int cmvae_causal_lc_bwd(const float* d_eps, const float* hid, const float* w2, int rows, float* d_pre,
+                                   float* part, void* stream) {
+    CMVAE_REQUIRE(d_eps && hid && w2 && d_pre && part && rows >= 1, "cmvae_causal_lc_bwd: bad arguments");
+    hipLaunchKernelGGL(causal_lc_bwd_kernel, dim3(cmvae_causal_lc_bwd_grid(rows)), dim3(512), 0, (hipStream_t)stream,
+                       d_eps, hid, w2, rows, d_pre, part);
+    return check_launch("causal_lc_bwd_kernel");
+}
+
+extern "C" int cmvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               void* stream) {
+    CMVAE_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && n % 4 == 0 && step >= 1,
+                  "cmvae_adam_step: bad arguments (n must be a multiple of 4, step >= 1)");
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)param,
+                       (const float4*)grad, (float4*)exp_avg, (float4*)exp_avg_sq, n / 4, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2));
+    return check_launch("adam_kernel");
+}

@@ -67,7 +67,7 @@ class FlatGrads:
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.flat = torch.zeros((n + 3) // 4 * 4, dtype=ref.dtype, device=ref.device)     # padded for float4 kernels
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -85,6 +85,11 @@ class FlatGrads:
 
 
 class _SyncBN(torch.autograd.Function):
+    """The C2 exchange step written out on torch tensors: what is summed, what is all-reduced and how the
+    backward uses the global sums.  The world_size-2 gloo tests run it on the CPU; on the GPU the same
+    exchange is `cmvae_amd.decoder._global_sums` between the HIP kernels (GEMM-epilogue partial sums ->
+    all-reduce -> cmvae_bn_finalize / cmvae_bn_bwd_finalize)."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
         C = x.shape[1]

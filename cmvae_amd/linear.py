@@ -1,0 +1,179 @@
+"""nn.Linear (+ReLU/ELU), the bulk NOTEARS-MLP causal layer and Adam on the HIP library.
+
+  * `linear(x, weight, bias, act)`  -- proj (omniglot/model.py:70-77; mimgnet/model.py:59-66), the
+    Set-Transformer projections and the (mu, logvar) head (omniglot/module.py:80-86, model.py:65-68):
+    forward, data gradient and weight gradient all run on the fp32-MFMA gather-GEMM kernels.
+  * `causal_mlp(x, fc1_w, fc1_b, w2, b2)` -- CausalEncoder.forward on bulk rows, nonlinear variant
+    (omniglot/module.py:165-188, 232-288): eps = x - LocallyConnected(elu(fc1(x))).
+  * `FlatAdam` -- torch.optim.Adam(lr, weight_decay) as one kernel over a flat parameter buffer
+    (omniglot/trainer.py:48-52).
+"""
+import torch
+
+from ._lib import lib, check
+
+ACT = {None: 0, 'none': 0, 'relu': 1, 'elu': 2}
+_p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t, name):
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError('cmvae_amd.linear: %s must be a float32 GPU tensor (there is no CPU path)' % name)
+
+
+_ws = {}
+
+
+def _workspace(nbytes, device):
+    ws = _ws.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws[device] = ws
+    return ws
+
+
+def linear_fwd(x2, weight, bias, act, out=None):
+    rows, in_f = x2.shape
+    out_f = weight.shape[0]
+    y = torch.empty(rows, out_f, device=x2.device, dtype=torch.float32) if out is None else out
+    check(lib.cmvae_linear_fwd(_p(x2), x2.stride(0), rows, in_f, out_f, _p(weight), _p(bias), act, _p(y),
+                               y.stride(0), _stream()), 'cmvae_linear_fwd')
+    return y
+
+
+def act_bwd(dy, y, act):
+    dz = torch.empty_like(y)
+    check(lib.cmvae_act_bwd(_p(dy), _p(y), y.numel(), act, _p(dz), _stream()), 'cmvae_act_bwd')
+    return dz
+
+
+def linear_bwd(x2, weight, dz, need_dx, need_db):
+    rows, in_f = x2.shape
+    out_f = weight.shape[0]
+    dx = torch.empty(rows, in_f, device=x2.device, dtype=torch.float32) if need_dx else None
+    dW = torch.empty_like(weight)
+    db = torch.empty(out_f, device=x2.device, dtype=torch.float32) if need_db else None
+    nbytes = lib.cmvae_linear_bwd_workspace_bytes(rows, in_f, out_f)
+    ws = _workspace(nbytes, x2.device)
+    check(lib.cmvae_linear_bwd(_p(x2), x2.stride(0), _p(weight), _p(dz), dz.stride(0), rows, in_f, out_f, _p(dx),
+                               in_f, _p(dW), _p(db), _p(ws), ws.numel(), _stream()), 'cmvae_linear_bwd')
+    return dx, dW, db
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        _need(x, 'x'); _need(weight, 'weight')
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        w = weight.contiguous()
+        y = linear_fwd(x2, w, None if bias is None else bias.contiguous(), act)
+        ctx.act, ctx.shape, ctx.has_bias = act, x.shape, bias is not None
+        ctx.save_for_backward(x2, w, y if act else None)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w.shape[0]).contiguous()
+        if x2.shape[0] == 0:
+            return torch.zeros(ctx.shape, device=dy.device), torch.zeros_like(w), \
+                (torch.zeros(w.shape[0], device=dy.device) if ctx.has_bias else None), None
+        dz = act_bwd(dy2, y, ctx.act) if ctx.act else dy2
+        dx, dW, db = linear_bwd(x2, w, dz, ctx.needs_input_grad[0], ctx.has_bias)
+        return (None if dx is None else dx.view(ctx.shape)), dW, db, None
+
+
+def linear(x, weight, bias=None, act=None):
+    """act(x @ weight^T + bias) on the HIP GEMM kernels; features must be multiples of 64 (<= 2048)."""
+    return _Linear.apply(x, weight, bias, ACT[act])
+
+
+class _CausalMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fc1_w, fc1_b, w2, b2):
+        _need(x, 'x')
+        x2 = x.reshape(-1, 64).contiguous()
+        w1, b1 = fc1_w.contiguous(), fc1_b.contiguous()
+        w2c, b2c = w2.reshape(64, 32).contiguous(), b2.reshape(64).contiguous()
+        hid = linear_fwd(x2, w1, b1, 2)                                   # [rows, 2048] = elu(fc1(x))
+        eps = torch.empty_like(x2)
+        check(lib.cmvae_causal_lc_fwd(_p(x2), _p(hid), _p(w2c), _p(b2c), x2.shape[0], _p(eps), _stream()),
+              'cmvae_causal_lc_fwd')
+        ctx.shape, ctx.w2_shape, ctx.b2_shape = x.shape, w2.shape, b2.shape
+        ctx.save_for_backward(x2, w1, w2c, hid)
+        return eps.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, d_eps):
+        x2, w1, w2c, hid = ctx.saved_tensors
+        rows = x2.shape[0]
+        g = d_eps.reshape(-1, 64).contiguous()
+        d_pre = torch.empty_like(hid)
+        nblk, L = lib.cmvae_causal_lc_bwd_grid(rows), lib.cmvae_causal_lc_bwd_partial_len()
+        part = torch.empty(nblk, L, device=g.device, dtype=torch.float32)
+        check(lib.cmvae_causal_lc_bwd(_p(g), _p(hid), _p(w2c), rows, _p(d_pre), _p(part), _stream()),
+              'cmvae_causal_lc_bwd')
+        red = torch.empty(L, device=g.device, dtype=torch.float32)
+        check(lib.cmvae_colsum_reduce(_p(part), nblk, L, _p(red), _stream()), 'cmvae_colsum_reduce')
+        dx1, dW1, db1 = linear_bwd(x2, w1, d_pre, ctx.needs_input_grad[0], True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (g + dx1).view(ctx.shape)
+        return dx, dW1, db1, red[:2048].view(ctx.w2_shape), red[2048:].view(ctx.b2_shape)
+
+
+def causal_mlp(x, fc1_w, fc1_b, w2, b2):
+    """eps = x - LocallyConnected(elu(fc1(x))) for x [..., 64]; w2 [64,32,1], b2 [64,1]."""
+    if x.numel() == 0:
+        return x.clone()
+    return _CausalMLP.apply(x, fc1_w, fc1_b, w2, b2)
+
+
+class FlatAdam:
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) over the parameters of a `dist.FlatGrads`.
+
+    The parameters are re-pointed at slices of one flat fp32 buffer (padded to a multiple of 4), the
+    gradients are the FlatGrads buffer, and one kernel launch does the whole update."""
+
+    def __init__(self, flat_grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = flat_grads.params
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.flat_grads = flat_grads
+        n = flat_grads.flat.numel()
+        dev = flat_grads.flat.device
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatAdam: parameters must live on the GPU (there is no CPU path)')
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            off += k
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.t = 0
+
+    def step(self):
+        self.t += 1
+        n = self.flat.numel()
+        check(lib.cmvae_adam_step(_p(self.flat), _p(self.flat_grads.flat), _p(self.exp_avg), _p(self.exp_avg_sq), n,
+                                  self.t, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                  _stream()), 'cmvae_adam_step')
+
+    def zero_grad(self):
+        self.flat_grads.zero()
+
+    def state_dict(self):
+        return {'step': self.t, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])

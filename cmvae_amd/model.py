@@ -6,9 +6,11 @@ Where the arithmetic runs:
   * EM loops, causal prior term, (I+CC^T)^-1, mixture log-likelihood (fwd+bwd),
     reparametrisation + log q (fwd+bwd), acyclicity expm trace (fwd+bwd), few-shot posterior
     + argmax: hand-written HIP kernels behind the C-ABI (cmvae_amd/ops.py).
-  * Dense contractions (conv / conv-transpose / linear / attention) and BatchNorm currently go
-    through PyTorch-ROCm ATen ops on the GPU (MIOpen / hipBLASLt) — scaffolding that the fused
-    fp32-MFMA kernels replace (DESIGN.md "status").
+  * conv / conv-transpose / BatchNorm / max-pool / BCE (cmvae_amd/encoder.py, decoder.py), every
+    nn.Linear (+ELU/ReLU), the bulk causal layer and Adam (cmvae_amd/linear.py): hand-written HIP
+    kernels on the fp32-MFMA gather-GEMM family.
+  * Still ATen on the GPU: the 4-head softmax attention core inside the two SABs and the scalar
+    loss arithmetic.
 There is no CPU path: tensors must live on the GPU and the HIP library must be loadable.
 """
 import math
@@ -16,12 +18,11 @@ import math
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from .module import OmniglotEncoder, OmniglotDecoder, SAB, CausalEncoder
+from .linear import linear
 from .decoder import decoder_bce, nhwc_perm
-from .encoder import encode_images
 
 _LOG_NORM = -0.5 * np.log(2 * np.pi)
 
@@ -74,6 +75,11 @@ class _GMVAEBase(nn.Module):
         idx = np.stack([np.random.choice(sample_size, self.component_size, replace=False)
                         for _ in range(batch_size)], 0).astype(np.int64)
         return torch.from_numpy(idx).to(device)
+
+    def _posterior_head(self, H):
+        """q_z_given_H: two SABs and the (mu, logvar) Linear (omniglot/model.py:62-68)."""
+        H = self.q_z_given_H[1](self.q_z_given_H[0](H))
+        return linear(H, self.q_z_given_H[2].weight, self.q_z_given_H[2].bias)
 
     def get_unsupervised_prior(self, z, init_idx=None):
         """(pi_k, mu_k, trace_k) after `unsupervised_em_iters` EM iterations; also returns logw."""
@@ -160,10 +166,8 @@ class OmniglotGMVAE(_GMVAEBase):
     def _encode(self, X):
         B, S = X.shape[:2]
         # HIP encoder; its output is channels-last, gather the columns back to the reference's c*4+pix order
-        H = encode_images(self.encoder, X.reshape(B * S, -1))
-        j = torch.arange(self.last_hidden_size, device=H.device)
-        H = H[:, (j % 4) * self.hidden_size + j // 4].view(B, S, self.last_hidden_size)
-        return self.q_z_given_H(H).split(self.latent_size, dim=-1)
+        H = self.encoder(X.reshape(B * S, -1)).view(B, S, self.last_hidden_size)
+        return self._posterior_head(H).split(self.latent_size, dim=-1)
 
     def forward(self, X, h_lambda, h_c, a_lambda, eps=None, init_idx=None, extras=None):
         B, S = X.shape[:2]
@@ -176,9 +180,11 @@ class OmniglotGMVAE(_GMVAEBase):
         q_eps = self.causal(q_z - q_z.mean(1, keepdim=True))
         A = self.causal.get_w()
         # proj: the last Linear's rows are permuted so H_rec comes out channels-last ([2,2,64] per image)
-        h = self.proj[:4](torch.cat([q_z, q_eps], -1).view(-1, 2 * D))
+        h = torch.cat([q_z, q_eps], -1).view(-1, 2 * D)
+        h = linear(h, self.proj[0].weight, self.proj[0].bias, 'elu')
+        h = linear(h, self.proj[2].weight, self.proj[2].bias, 'elu')
         perm = nhwc_perm(h.device)
-        H_rec = F.elu(F.linear(h, self.proj[4].weight[perm], self.proj[4].bias[perm]))
+        H_rec = linear(h, self.proj[4].weight[perm], self.proj[4].bias[perm], 'elu')
         # decoder + Bernoulli likelihood: one fused HIP pipeline (cmvae_amd/decoder.py)
         p_rec, bce_sum = decoder_bce(self.decoder, H_rec, X.reshape(B * S, -1), M)
         X_rec = p_rec.view(B, S, M, *self.input_shape)
@@ -206,6 +212,8 @@ class FeatureGMVAE(_GMVAEBase):
         self._init_common(unsupervised_em_iters, semisupervised_em_iters, fix_pi, component_size, latent_size,
                           train_mc_sample_size, test_mc_sample_size, linear, laplace, gamma)
         self.input_shape = Fd = int(input_shape)
+        if Fd % 64 or Fd > 1024:
+            raise ValueError('the MI355X GEMM kernels need a feature size that is a multiple of 64, <= 1024 (got %d)' % Fd)
         self.q_z_given_H = nn.Sequential(SAB(Fd, Fd, 4, ln=False), SAB(Fd, Fd, 4, ln=False),
                                          nn.Linear(Fd, 2 * latent_size))
         self.causal = CausalEncoder(latent_size, linear=linear)
@@ -217,14 +225,17 @@ class FeatureGMVAE(_GMVAEBase):
     def forward(self, H, h_lambda, h_c, a_lambda, eps=None, init_idx=None, extras=None):
         B, S = H.shape[:2]
         M, D = self.train_mc_sample_size, self.latent_size
-        q_mean, q_logvar = self.q_z_given_H(H).split(D, dim=-1)
+        q_mean, q_logvar = self._posterior_head(H).split(D, dim=-1)
         if eps is None:
             eps = self._draw_eps(q_mean, M)
         q_z4, log_q_z = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
         q_z = q_z4.view(B, S * M, D)
         q_eps = self.causal(q_z)
         A = self.causal.get_w()
-        H_rec = self.proj(torch.cat([q_z, q_eps], -1).view(-1, 2 * D)).view(B, S, M, self.input_shape)
+        h = torch.cat([q_z, q_eps], -1).view(-1, 2 * D)
+        for i in (0, 2, 4):
+            h = linear(h, self.proj[i].weight, self.proj[i].bias, 'relu')
+        H_rec = h.view(B, S, M, self.input_shape)
         rec_loss = (H_rec - H[:, :, None]).pow(2).sum() / (B * S * M)
         kl_loss, h_augment, h = self._kl_and_h(q_z, log_q_z, q_eps, A, h_lambda, h_c, a_lambda, init_idx, extras)
         if extras is not None:
@@ -234,5 +245,5 @@ class FeatureGMVAE(_GMVAEBase):
     def prediction(self, H_tr, y_tr, H_te, eps=None, extras=None):
         tr, te = H_tr.shape[1], H_te.shape[1]
         with torch.no_grad():
-            q_mean, q_logvar = self.q_z_given_H(torch.cat([H_tr, H_te], dim=1)).split(self.latent_size, dim=-1)
+            q_mean, q_logvar = self._posterior_head(torch.cat([H_tr, H_te], dim=1)).split(self.latent_size, dim=-1)
             return self._predict_from_posterior(q_mean, q_logvar, y_tr, tr, te, eps, extras)

@@ -14,58 +14,30 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import dist as _dist
+from .linear import linear as _linear, causal_mlp as _causal_mlp
 
 
 class EpisodeBatchNorm2d(nn.BatchNorm2d):
-    """BatchNorm2d whose training statistics span the whole meta-batch, across ranks.
-
-    The reference normalises over all B*S (encoder) / B*S*M (decoder) images of the step
-    (omniglot/module.py:15-31, 51-59).  When the episodes are sharded over GPUs the per-channel
-    sums are all-reduced (collective C2) so the numbers do not depend on the
-    number of ranks.  Single-rank behaviour equals nn.BatchNorm2d.
-    """
+    """Parameters and running statistics of a BatchNorm2d whose training statistics span the whole
+    meta-batch, across ranks (omniglot/module.py:15-31, 51-59; SURVEY.md §5, collective C2).  The
+    arithmetic lives in the HIP pipelines (cmvae_amd/encoder.py, decoder.py: GEMM-epilogue sums ->
+    all-reduce -> cmvae_bn_finalize); this class only holds the state under the reference's keys."""
 
     def forward(self, x):
-        if self.training:
-            return _dist.sync_batch_norm(x, self)
-        C = x.shape[1]
-        scale = self.weight * torch.rsqrt(self.running_var + self.eps)
-        shift = self.bias - self.running_mean * scale
-        return x * scale.view(1, C, 1, 1) + shift.view(1, C, 1, 1)
-
-
-class GemmConv2d(nn.Conv2d):
-    """3x3 / stride 1 / pad 1 convolution as im2col + GEMM (no JIT-compiled library kernels)."""
-
-    def forward(self, x):
-        n, _, h, w = x.shape
-        cols = F.unfold(x, 3, padding=1)                               # [n, cin*9, h*w]
-        out = self.weight.view(self.out_channels, -1).matmul(cols)      # [n, cout, h*w]
-        return out.view(n, self.out_channels, h, w) + self.bias.view(1, -1, 1, 1)
-
-
-class GemmConvTranspose2d(nn.ConvTranspose2d):
-    """k x k / stride 2 / pad 1 transposed convolution as GEMM + col2im."""
-
-    def forward(self, x):
-        n, cin, h, w = x.shape
-        k = self.kernel_size[0]
-        ho, wo = (h - 1) * 2 - 2 + k, (w - 1) * 2 - 2 + k
-        cols = self.weight.view(cin, -1).t().matmul(x.reshape(n, cin, h * w))   # [n, cout*k*k, h*w]
-        out = F.fold(cols, (ho, wo), k, padding=1, stride=2)
-        return out + self.bias.view(1, -1, 1, 1)
+        raise RuntimeError('EpisodeBatchNorm2d is a parameter container: run the encoder / decoder through '
+                           'cmvae_amd.encoder.encode_images / cmvae_amd.decoder.decoder_bce')
 
 
 def _conv_block(cin, cout):
-    return [GemmConv2d(cin, cout, 3, 1, 1), EpisodeBatchNorm2d(cout), nn.ReLU(inplace=True),
+    return [nn.Conv2d(cin, cout, 3, 1, 1), EpisodeBatchNorm2d(cout), nn.ReLU(inplace=True),
             nn.MaxPool2d(2, ceil_mode=True)]
 
 
 class OmniglotEncoder(nn.Module):
-    """28x28 -> 14 -> 7 -> 4 -> 2, flattened to 4*hidden features."""
+    """28x28 -> 14 -> 7 -> 4 -> 2, flattened to 4*hidden features (parameter container; the HIP
+    pipeline is cmvae_amd.encoder.encode_images)."""
 
     def __init__(self, hidden_size):
         super().__init__()
@@ -76,24 +48,30 @@ class OmniglotEncoder(nn.Module):
         self.encoder = nn.Sequential(*layers)
 
     def forward(self, x):
-        return self.encoder(x).reshape(-1, self.last_hidden_size)
+        """x [n,1,28,28] (or [n,784]) -> [n, 4*hidden] in the reference's c*4+pix column order."""
+        from .encoder import encode_images
+        H = encode_images(self, x.reshape(x.shape[0], -1))
+        j = torch.arange(self.last_hidden_size, device=H.device)
+        hs = self.last_hidden_size // 4
+        return H[:, (j % 4) * hs + j // 4]
 
 
 class OmniglotDecoder(nn.Module):
-    """[*, 4*hidden] -> view [*, hidden, 2, 2] -> 4 -> 7 -> 14 -> 28 (sigmoid)."""
+    """[*, 4*hidden] -> view [*, hidden, 2, 2] -> 4 -> 7 -> 14 -> 28 (sigmoid).  Parameter container; the
+    HIP pipeline (fused with the Bernoulli likelihood) is cmvae_amd.decoder.decoder_bce."""
 
     def __init__(self, hidden_size):
         super().__init__()
         self.hidden_size = hidden_size
         h = hidden_size
         self.decoder = nn.Sequential(
-            GemmConvTranspose2d(h, h, 4, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
-            GemmConvTranspose2d(h, h, 3, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
-            GemmConvTranspose2d(h, h, 4, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
-            GemmConvTranspose2d(h, 1, 4, 2, 1), nn.Sigmoid())
+            nn.ConvTranspose2d(h, h, 4, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(h, h, 3, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(h, h, 4, 2, 1), EpisodeBatchNorm2d(h), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(h, 1, 4, 2, 1), nn.Sigmoid())
 
     def forward(self, h):
-        return self.decoder(h.view(-1, self.hidden_size, 2, 2))
+        raise RuntimeError('OmniglotDecoder is a parameter container: use cmvae_amd.decoder.decoder_bce')
 
 
 class MAB(nn.Module):
@@ -112,16 +90,16 @@ class MAB(nn.Module):
     def forward(self, Q, K):
         B, S, _ = Q.shape
         hd = self.dim_V // self.num_heads
-        q = self.fc_q(Q)
-        k = self.fc_k(K)
-        v = self.fc_v(K)
+        q = _linear(Q, self.fc_q.weight, self.fc_q.bias)
+        k = _linear(K, self.fc_k.weight, self.fc_k.bias)
+        v = _linear(K, self.fc_v.weight, self.fc_v.bias)
         # heads as a batch axis; same arithmetic as the reference's split/cat-on-batch form
         qh = q.view(B, S, self.num_heads, hd).transpose(1, 2)
         kh = k.view(B, -1, self.num_heads, hd).transpose(1, 2)
         vh = v.view(B, -1, self.num_heads, hd).transpose(1, 2)
         att = torch.softmax(qh.matmul(kh.transpose(-1, -2)) / math.sqrt(self.dim_V), -1)
         o = (qh + att.matmul(vh)).transpose(1, 2).reshape(B, S, self.dim_V)
-        return o + F.relu(self.fc_o(o))
+        return o + _linear(o, self.fc_o.weight, self.fc_o.bias, 'relu')
 
 
 class SAB(nn.Module):
@@ -170,16 +148,11 @@ class CausalEncoder(nn.Module):
             self.fc2 = nn.ModuleList([LocallyConnected(latent_size, self.dims[1], self.dims[2], bias=bias)])
             nn.init.xavier_normal_(self.fc1.weight.data)       # bias keeps nn.Linear's default init
 
-    def mask(self, x):
-        if self.linear:
-            return x.matmul(self.A)
-        h = self.fc1(x).view(-1, self.dims[0], self.dims[1])
-        for fc in self.fc2:
-            h = fc(F.elu(h))
-        return h.squeeze(2).view(x.shape)
-
     def forward(self, x):
-        return x - self.mask(x)
+        """eps = x - mask(x) on the HIP kernels (bulk rows; the EM loop uses cmvae_causal_rows instead)."""
+        if self.linear:
+            return x - _linear(x, self.A.t().contiguous())
+        return _causal_mlp(x, self.fc1.weight, self.fc1.bias, self.fc2[0].weight, self.fc2[0].bias)
 
     def get_w(self):
         if self.linear:

@@ -144,7 +144,7 @@ typedef struct cmvae_conv_geom {
     int32_t rows_total, Hg, Wg, Hi, Wi, sy, sx, Ho, Wo, oys, oxs, oy0, ox0, ntaps;
     int32_t a_pitch, o_pitch, w_pitch;
     int64_t w_tap_stride, w_nblk_stride;
-    int32_t dy[16], dx[16], a_col[16];
+    int32_t dy[32], dx[32], a_col[32];
 } cmvae_conv_geom;
 
 /* act: 0 none, 1 ReLU, 2 ELU.  stats_part (optional, n_col_blocks == 1): per-block partial
@@ -163,6 +163,38 @@ int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, const float* a
                      const float* G, int g_pitch, int g_col, const int64_t* tap_off_host,
                      int64_t s_ci, int64_t s_co, float* dW, float* db, int accumulate_db,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ==== nn.Linear (+ReLU/ELU) on the gather-GEMM kernels: proj (omniglot/model.py:70-77, mimgnet/model.py:59-66),
+ * the Set-Transformer projections fc_q/k/v/o and the (mu, logvar) head (omniglot/module.py:80-86, model.py:65-68),
+ * CausalEncoder.fc1 (omniglot/module.py:148,181).  W [out_f,in_f] as torch stores it; features are multiples of
+ * 64, at most 2048.  Y = act(X W^T + bias); act: 0 none, 1 ReLU, 2 ELU.                                       */
+int cmvae_linear_fwd(const float* X, int x_pitch, int rows, int in_f, int out_f, const float* W,
+                     const float* bias, int act, float* Y, int y_pitch, void* stream);
+/* dZ = dY * act'(.) from the saved output Y (n elements, n % 4 == 0; act 1 or 2).                         */
+int cmvae_act_bwd(const float* dY, const float* Y, int64_t n, int act, float* dZ, void* stream);
+/* dX = dZ W (skipped when dX == NULL), dW[out_f,in_f] = dZ^T X, db[out_f] = column sums of dZ (may be NULL). */
+size_t cmvae_linear_bwd_workspace_bytes(int rows, int in_f, int out_f);
+int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, const float* dZ, int dz_pitch, int rows,
+                     int in_f, int out_f, float* dX, int dx_pitch, float* dW, float* db,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ==== NOTEARS-MLP causal layer on bulk rows (CausalEncoder.forward on [B*N,64], omniglot/module.py:165-188,
+ * LocallyConnected :232-288).  hid [rows,2048] = elu(fc1(x)) comes from cmvae_linear_fwd(act=2);
+ * eps[r][j] = x[r][j] - (sum_m hid[r][32j+m] w2[j][m] + b2[j]).
+ * Backward: d_pre [rows,2048] = gradient at fc1's pre-activation (feeds cmvae_linear_bwd) and
+ * part [cmvae_causal_lc_bwd_grid(rows)][cmvae_causal_lc_bwd_partial_len()] = {dw2[64][32], db2[64]} per block
+ * (reduce with cmvae_colsum_reduce).                                                                        */
+int cmvae_causal_lc_fwd(const float* x, const float* hid, const float* w2, const float* b2, int rows,
+                        float* eps, void* stream);
+int cmvae_causal_lc_bwd_grid(int rows);
+int cmvae_causal_lc_bwd_partial_len(void);
+int cmvae_causal_lc_bwd(const float* d_eps, const float* hid, const float* w2, int rows, float* d_pre,
+                        float* part, void* stream);
+
+/* ==== Adam with L2 weight decay over one flat parameter buffer (torch.optim.Adam as configured in
+ * omniglot/trainer.py:48-52); step counts from 1; n % 4 == 0.                                               */
+int cmvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ==== BatchNorm (training statistics over the whole meta-batch) on channels-last [rows,64]
  * nn.BatchNorm2d after every conv (omniglot/module.py:15,20,25,30,51,55,59).  The conv GEMM

@@ -18,8 +18,13 @@ def _free_port():
     return p
 
 
+class EpisodeBatchNorm2d(nn.BatchNorm2d):
+    def forward(self, x):
+        from cmvae_amd import dist as cdist
+        return cdist.sync_batch_norm(x, self) if self.training else super().forward(x)
+
+
 def _net():
-    from cmvae_amd.module import EpisodeBatchNorm2d
     torch.manual_seed(3)
     return nn.Sequential(nn.Conv2d(1, 4, 3, 1, 1), EpisodeBatchNorm2d(4), nn.ReLU(), nn.Conv2d(4, 2, 3, 1, 1),
                          EpisodeBatchNorm2d(2))

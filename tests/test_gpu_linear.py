@@ -1,0 +1,103 @@
+"""Parity of the Linear / bulk causal-MLP / Adam entry points (through the C-ABI) against the oracle's
+plain PyTorch fp32 restatement on the CPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+ACTS = {None: lambda v: v, 'relu': F.relu, 'elu': F.elu}
+
+
+@pytest.mark.parametrize('rows,in_f,out_f,act', [
+    (300, 128, 256, 'elu'), (1000, 256, 256, 'relu'), (77, 64, 2048, 'elu'), (513, 2048, 64, None),
+    (1, 256, 128, None), (1200, 512, 512, 'relu'), (129, 64, 64, None)])
+def test_linear_fwd_bwd(rows, in_f, out_f, act):
+    from cmvae_amd.linear import linear
+    g = torch.Generator().manual_seed(rows + in_f)
+    x = torch.randn(rows, in_f, generator=g)
+    W = torch.randn(out_f, in_f, generator=g) / np.sqrt(in_f)
+    b = torch.randn(out_f, generator=g) * 0.1
+    gy = torch.randn(rows, out_f, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    yr = ACTS[act](F.linear(xr, Wr, br))
+    yr.backward(gy)
+    xd, Wd, bd = (t.cuda().requires_grad_(True) for t in (x, W, b))
+    yd = linear(xd, Wd, bd, act)
+    yd.backward(gy.cuda())
+    assert _rel(yd, yr) < 1e-5
+    assert _rel(xd.grad, xr.grad) < 1e-5
+    assert _rel(Wd.grad, Wr.grad) < 2e-5
+    assert _rel(bd.grad, br.grad) < 2e-5
+
+
+def test_linear_batched_shape_no_bias_no_input_grad():
+    from cmvae_amd.linear import linear
+    x = torch.randn(4, 50, 256)
+    W = torch.randn(128, 256) / 16
+    yd = linear(x.cuda(), W.cuda().requires_grad_(True), None, None)
+    assert yd.shape == (4, 50, 128)
+    assert _rel(yd, F.linear(x, W)) < 1e-5
+    yd.sum().backward()
+
+
+def test_linear_rejects_bad_sizes():
+    from cmvae_amd.linear import linear
+    with pytest.raises(RuntimeError):
+        linear(torch.randn(8, 100).cuda(), torch.randn(64, 100).cuda())
+    with pytest.raises(RuntimeError):
+        linear(torch.randn(8, 64), torch.randn(64, 64))
+
+
+@pytest.mark.parametrize('rows', [1, 200, 1500])
+def test_causal_mlp_bulk(rows):
+    from cmvae_amd.linear import causal_mlp
+    from oracle.gmvae_oracle import causal
+    g = torch.Generator().manual_seed(rows)
+    P = {'causal.fc1.weight': torch.randn(2048, 64, generator=g) * 0.05,
+         'causal.fc1.bias': torch.randn(2048, generator=g) * 0.1,
+         'causal.fc2.0.weight': torch.randn(64, 32, 1, generator=g) * 0.2,
+         'causal.fc2.0.bias': torch.randn(64, 1, generator=g) * 0.1}
+    x = torch.randn(rows, 64, generator=g)
+    gy = torch.randn(rows, 64, generator=g)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    er = causal(xr, Pr, linear=False)
+    er.backward(gy)
+    Pd = {k: v.cuda().requires_grad_(True) for k, v in P.items()}
+    xd = x.cuda().requires_grad_(True)
+    ed = causal_mlp(xd, Pd['causal.fc1.weight'], Pd['causal.fc1.bias'], Pd['causal.fc2.0.weight'],
+                    Pd['causal.fc2.0.bias'])
+    ed.backward(gy.cuda())
+    assert _rel(ed, er) < 1e-5
+    assert _rel(xd.grad, xr.grad) < 1e-5
+    for k in P:
+        assert _rel(Pd[k].grad, Pr[k].grad) < 3e-5, k
+
+
+def test_flat_adam_matches_torch_adam():
+    from cmvae_amd.dist import FlatGrads
+    from cmvae_amd.linear import FlatAdam
+    torch.manual_seed(3)
+    shapes = [(64, 64), (7,), (33, 5), (2048, 64), (1,)]
+    ref = [torch.randn(s).requires_grad_(True) for s in shapes]
+    dev = [r.detach().clone().cuda().requires_grad_(True) for r in ref]
+    opt_r = torch.optim.Adam(ref, lr=1e-3, weight_decay=5e-5)
+    fg = FlatGrads(dev)
+    opt_d = FlatAdam(fg, lr=1e-3, weight_decay=5e-5)
+    for it in range(5):
+        for r, d in zip(ref, dev):
+            gr = torch.randn(r.shape) * (it + 1)
+            r.grad = gr.clone()
+            d.grad.copy_(gr)
+        opt_r.step()
+        opt_d.step()
+    for r, d in zip(ref, dev):
+        assert _rel(d, r) < 1e-6

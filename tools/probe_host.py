@@ -7,7 +7,8 @@ from cmvae_amd import dist as cdist
 dev = torch.device('cuda:0')
 model = bench.build_model(dev)
 flat = cdist.FlatGrads(model.parameters())
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-5, fused=True)
+from cmvae_amd.linear import FlatAdam
+opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
 np.random.seed(1); torch.manual_seed(1)
 X = bench.synth_images(bench.B_PER_GPU, bench.SAMPLE, 'cpu', 100).to(dev)
 N = bench.SAMPLE * bench.MC
