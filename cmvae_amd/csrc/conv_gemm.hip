@@ -287,6 +287,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
     const int ci_h = w >> 1, co_h = w & 1;
     const bool has_t = a_scale != nullptr;
     const int ntiles = (g.rows_total + BM - 1) / BM;
+    // grid.y walks 64-column blocks of G, grid.z groups of NT taps; every (y, z) owns a slab of partials
+    tap0 += NT * blockIdx.z;
+    g_col += 64 * blockIdx.y;
+    {
+        const long slot = (long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x;
+        part += slot * NT * 4096;
+        if (db_part) db_part += slot * 64;
+        if (blockIdx.z != 0) db_part = nullptr;
+    }
     floatx16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = floatx16{};
@@ -356,10 +365,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
     }
 }
 
-// out[tap_off[t] + ci*s_ci + co*s_co] = sum_blk part[blk][t][ci][co];  db[co] = sum_blk db_part[blk][co]
+// out[y*y_stride + tap_off[NT*z + t] + ci*s_ci + co*s_co] = sum_blk part[(z,y)][blk][t][ci][co];
+// db[64*y + co] = sum_blk db_part[(0,y)][blk][co]
 struct WgradOut {
-    long tap_off[4];
-    long s_ci, s_co;
+    long tap_off[32];
+    long s_ci, s_co, y_stride;
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nblk, int NT,
                                                            WgradOut o, float* __restrict__ dW,
@@ -369,18 +379,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     __shared__ float red[4 * 64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + c;
-    const bool is_db = blockIdx.x == gridDim.x - 1 && db != nullptr;     // last workgroup: the bias gradient
+    const long slot = (long)(blockIdx.z * gridDim.y + blockIdx.y) * nblk;
+    part += slot * NT * 4096;
+    const bool is_db = blockIdx.x == NT * 64;                  // extra workgroup: the bias gradient
+    if (is_db && (db == nullptr || blockIdx.z != 0)) return;
     float s0 = 0.f, s1 = 0.f;
     if (!is_db) {
-        if (e < NT * 4096) {
-            int b = g;
-            for (; b + 4 < nblk; b += 8) {
-                s0 += part[(long)b * NT * 4096 + e];
-                s1 += part[(long)(b + 4) * NT * 4096 + e];
-            }
-            if (b < nblk) s0 += part[(long)b * NT * 4096 + e];
+        int b = g;
+        for (; b + 4 < nblk; b += 8) {
+            s0 += part[(long)b * NT * 4096 + e];
+            s1 += part[(long)(b + 4) * NT * 4096 + e];
         }
+        if (b < nblk) s0 += part[(long)b * NT * 4096 + e];
     } else {
+        db_part += slot * 64;
         for (int b = g; b < nblk; b += 4) s0 += db_part[(long)b * 64 + c];
     }
     red[g * 64 + c] = s0 + s1;
@@ -388,12 +400,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (g != 0) return;
     const float s = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
     if (!is_db) {
-        if (e < NT * 4096) {
-            const int t = e >> 12, ci = (e >> 6) & 63, co = e & 63;
-            dW[o.tap_off[t] + ci * o.s_ci + co * o.s_co] = s;
-        }
+        const int t = e >> 12, ci = (e >> 6) & 63, co = e & 63;
+        dW[blockIdx.y * o.y_stride + o.tap_off[NT * blockIdx.z + t] + ci * o.s_ci + co * o.s_co] = s;
     } else {
-        db[c] = accumulate_db ? db[c] + s : s;
+        float* d = db + 64 * blockIdx.y;
+        d[c] = accumulate_db ? d[c] + s : s;
     }
 }
 
@@ -473,30 +484,42 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
 }
 
 extern "C" size_t cmvae_conv_wgrad_workspace_bytes(int rows_total) {
-    const int nblk = wgrad_grid(rows_total);
+    (void)rows_total;
+    const int nblk = wgrad_grid(1 << 30);      // sized for the full grid: column/tap blocks share it
     return align_up((size_t)nblk * 4 * 4096 * sizeof(float)) + align_up((size_t)nblk * 64 * sizeof(float));
 }
 
+// ny 64-column blocks of G (dW advances by y_stride per block) x the taps of g, in as few launches as possible
 static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale, const float* a_shift,
                         const float* G, int g_pitch, int g_col, const int64_t* tap_off_host, int64_t s_ci,
-                        int64_t s_co, float* dW, float* db, int accumulate_db, void* workspace, hipStream_t st) {
-    const int nblk = wgrad_grid(g.rows_total);
+                        int64_t s_co, float* dW, float* db, int accumulate_db, void* workspace, hipStream_t st,
+                        int ny = 1, int64_t y_stride = 0) {
+    const int nt_launch = g.ntaps < 4 ? g.ntaps : 4;
+    const int nz_all = g.ntaps % nt_launch == 0 ? g.ntaps / nt_launch : 1;       // tap groups in grid.z when uniform
+    const int max_blocks = wgrad_grid(1 << 30);
+    int nblk = max_blocks / (ny * nz_all);
+    const int ntiles = (g.rows_total + BM - 1) / BM;
+    if (nblk < 1) nblk = 1;
+    if (nblk > ntiles) nblk = ntiles;
     float* part = (float*)workspace;
-    float* db_part = (float*)((char*)workspace + align_up((size_t)nblk * 4 * 4096 * sizeof(float)));
-    for (int t0 = 0; t0 < g.ntaps; t0 += 4) {
-        const int nt = g.ntaps - t0 < 4 ? g.ntaps - t0 : 4;
+    float* db_part = (float*)((char*)workspace + align_up((size_t)max_blocks * 4 * 4096 * sizeof(float)));
+    if ((long)nblk * ny * nz_all > max_blocks) return set_error("wgrad: %d x %d column/tap blocks exceed the workspace", ny, nz_all);
+    WgradOut o{};
+    o.s_ci = s_ci; o.s_co = s_co; o.y_stride = y_stride;
+    for (int t0 = 0; t0 < g.ntaps; t0 += nt_launch * nz_all) {
+        const int nt = g.ntaps - t0 < nt_launch ? g.ntaps - t0 : nt_launch;
+        const int nz = nz_all > 1 ? nz_all : 1;
         float* dbp = (db && t0 == 0) ? db_part : nullptr;
+        const dim3 grid(nblk, ny, nz);
         switch (nt) {
-            case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(nblk), dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            case 2: hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3(nblk), dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3(nblk), dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            default: hipLaunchKernelGGL(conv_wgrad_kernel<4>, dim3(nblk), dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 2: hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            default: hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
         }
         if (int e = check_launch("conv_wgrad_kernel")) return e;
-        WgradOut o{};
-        for (int t = 0; t < nt; ++t) o.tap_off[t] = tap_off_host[t0 + t];
-        o.s_ci = s_ci; o.s_co = s_co;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nt * 64 + (dbp ? 1 : 0)), dim3(256), 0, st, part, nblk, nt, o, dW,
+        for (int t = 0; t < nt * nz; ++t) o.tap_off[t] = tap_off_host[t0 + t];
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nt * 64 + 1, ny, nz), dim3(256), 0, st, part, nblk, nt, o, dW,
                            dbp, dbp ? db : nullptr, accumulate_db);
         if (int e = check_launch("wgrad_reduce_kernel")) return e;
     }
@@ -637,22 +660,19 @@ extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, con
     }
     // dW[o][i] = sum_r dZ[r][o] X[r][i]: the operand with more 64-column blocks supplies the taps (4 per launch)
     int64_t tap_off[32];
-    if (kout * ((kin + 3) / 4) <= kin * ((kout + 3) / 4)) {
+    const bool taps_over_in = kout * ((kin + 3) / 4) <= kin * ((kout + 3) / 4);
+    if (taps_over_in) {
         const ConvGeom g = linear_geom(rows, in_f, 64, x_pitch, 64);
-        for (int cb = 0; cb < kout; ++cb) {
-            for (int t = 0; t < kin; ++t) tap_off[t] = 64L * cb * in_f + 64 * t;
-            if (int e = wgrad_launch(g, X, nullptr, nullptr, dZ, dz_pitch, 64 * cb, tap_off, 1, in_f, dW,
-                                     db ? db + 64 * cb : nullptr, 0, wg_ws, st))
-                return e;
-        }
+        for (int t = 0; t < kin; ++t) tap_off[t] = 64 * t;
+        if (int e = wgrad_launch(g, X, nullptr, nullptr, dZ, dz_pitch, 0, tap_off, 1, in_f, dW, db, 0, wg_ws, st, kout,
+                                 64L * in_f))
+            return e;
     } else {
         const ConvGeom g = linear_geom(rows, out_f, 64, dz_pitch, 64);
-        for (int cb = 0; cb < kin; ++cb) {
-            for (int t = 0; t < kout; ++t) tap_off[t] = 64L * t * in_f + 64 * cb;
-            if (int e = wgrad_launch(g, dZ, nullptr, nullptr, X, x_pitch, 64 * cb, tap_off, in_f, 1, dW, nullptr, 0,
-                                     wg_ws, st))
-                return e;
-        }
+        for (int t = 0; t < kout; ++t) tap_off[t] = 64L * t * in_f;
+        if (int e = wgrad_launch(g, dZ, nullptr, nullptr, X, x_pitch, 0, tap_off, in_f, 1, dW, nullptr, 0, wg_ws, st,
+                                 kin, 64))
+            return e;
         if (db) {
             const int nb = rows < COLSUM_BLOCKS ? rows : COLSUM_BLOCKS;
             hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, dZ, rows, out_f, dz_pitch, cs_part);

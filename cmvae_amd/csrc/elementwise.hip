@@ -232,15 +232,16 @@ __global__ __launch_bounds__(256) void causal_lc_fwd_kernel(const float* __restr
 }
 
 // backward of the tail: g = -d_eps[r][j];  d_pre[r][32j+m] = g * w2[j][m] * elu'(.);  per-block partials of
-// dw2[j][m] = sum_r g * hid[r][32j+m] and db2[j] = sum_r g.  512 threads = one float4 of every hidden column.
-constexpr int LC_BWD_L = HID + D;
+// dw2[j][m] = sum_r g * hid[r][32j+m], db2[j] = sum_r g and db1 = column sums of d_pre (fc1's bias gradient).
+// 512 threads = one float4 of every hidden column.
+constexpr int LC_BWD_L = HID + D + HID;
 __global__ __launch_bounds__(512) void causal_lc_bwd_kernel(const float* __restrict__ d_eps,
                                                             const float* __restrict__ hid,
                                                             const float* __restrict__ w2, int rows,
                                                             float* __restrict__ d_pre, float* __restrict__ part) {
     const int t = threadIdx.x, j = t >> 3;
     const float4 w = *reinterpret_cast<const float4*>(w2 + 4 * t);
-    float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dw = make_float4(0.f, 0.f, 0.f, 0.f), d1 = make_float4(0.f, 0.f, 0.f, 0.f);
     float db = 0.f;
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         const float g = -d_eps[(long)r * D + j];
@@ -253,11 +254,13 @@ __global__ __launch_bounds__(512) void causal_lc_bwd_kernel(const float* __restr
         *reinterpret_cast<float4*>(d_pre + (long)r * HID + 4 * t) = o;
         dw.x = fmaf(g, h.x, dw.x); dw.y = fmaf(g, h.y, dw.y);
         dw.z = fmaf(g, h.z, dw.z); dw.w = fmaf(g, h.w, dw.w);
+        d1.x += o.x; d1.y += o.y; d1.z += o.z; d1.w += o.w;
         db += g;
     }
     float* pb = part + (long)blockIdx.x * LC_BWD_L;
     *reinterpret_cast<float4*>(pb + 4 * t) = dw;
     if ((t & 7) == 0) pb[HID + j] = db;
+    *reinterpret_cast<float4*>(pb + HID + D + 4 * t) = d1;
 }
 
 // ---------------------------------------------------------------- Adam with L2 weight decay (torch.optim.Adam)

@@ -121,11 +121,11 @@ class _CausalMLP(torch.autograd.Function):
               'cmvae_causal_lc_bwd')
         red = torch.empty(L, device=g.device, dtype=torch.float32)
         check(lib.cmvae_colsum_reduce(_p(part), nblk, L, _p(red), _stream()), 'cmvae_colsum_reduce')
-        dx1, dW1, db1 = linear_bwd(x2, w1, d_pre, ctx.needs_input_grad[0], True)
+        dx1, dW1, _ = linear_bwd(x2, w1, d_pre, ctx.needs_input_grad[0], False)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = (g + dx1).view(ctx.shape)
-        return dx, dW1, db1, red[:2048].view(ctx.w2_shape), red[2048:].view(ctx.b2_shape)
+        return dx, dW1, red[2112:], red[:2048].view(ctx.w2_shape), red[2048:2112].view(ctx.b2_shape)
 
 
 def causal_mlp(x, fc1_w, fc1_b, w2, b2):

@@ -182,7 +182,7 @@ int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, const float* d
  * LocallyConnected :232-288).  hid [rows,2048] = elu(fc1(x)) comes from cmvae_linear_fwd(act=2);
  * eps[r][j] = x[r][j] - (sum_m hid[r][32j+m] w2[j][m] + b2[j]).
  * Backward: d_pre [rows,2048] = gradient at fc1's pre-activation (feeds cmvae_linear_bwd) and
- * part [cmvae_causal_lc_bwd_grid(rows)][cmvae_causal_lc_bwd_partial_len()] = {dw2[64][32], db2[64]} per block
+ * part [cmvae_causal_lc_bwd_grid(rows)][cmvae_causal_lc_bwd_partial_len()] = {dw2[64][32], db2[64], db1[2048]} per block
  * (reduce with cmvae_colsum_reduce).                                                                        */
 int cmvae_causal_lc_fwd(const float* x, const float* hid, const float* w2, const float* b2, int rows,
                         float* eps, void* stream);
