@@ -96,6 +96,10 @@ SIGNATURES = {
     'cmvae_causal_lc_bwd_grid': (c_int, [c_int]),
     'cmvae_causal_lc_bwd_partial_len': (c_int, []),
     'cmvae_causal_lc_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'cmvae_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                    c_void_p]),
+    'cmvae_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cmvae_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float,
                                 c_float, c_float, c_void_p]),
 }

@@ -135,6 +135,41 @@ def causal_mlp(x, fc1_w, fc1_b, w2, b2):
     return _CausalMLP.apply(x, fc1_w, fc1_b, w2, b2)
 
 
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
+            _need(t, n)
+        B, S, C = q.shape
+        if C != 64 * heads or k.shape != q.shape or v.shape != q.shape:
+            raise RuntimeError('cmvae_amd attention: heads of 64 channels and equal Q/K/V shapes are required '
+                               '(got %s, %d heads)' % (tuple(q.shape), heads))
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o = torch.empty_like(q)
+        lse = torch.empty(B, heads, S, device=q.device, dtype=torch.float32)
+        check(lib.cmvae_attention_fwd(_p(q), _p(k), _p(v), B, S, heads, scale, _p(o), _p(lse), _stream()),
+              'cmvae_attention_fwd')
+        ctx.heads, ctx.scale = heads, scale
+        ctx.save_for_backward(q, k, v, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, lse = ctx.saved_tensors
+        B, S, _ = q.shape
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        delta = torch.empty_like(lse)
+        check(lib.cmvae_attention_bwd(_p(q), _p(k), _p(v), _p(lse), _p(do), B, S, ctx.heads, ctx.scale, _p(dq), _p(dk),
+                                      _p(dv), _p(delta), _stream()), 'cmvae_attention_bwd')
+        return dq, dk, dv, None, None
+
+
+def attention(q, k, v, heads, scale):
+    """q + softmax(scale * q k^T) v per (episode, head) for [B, S, heads*64] tensors (MAB core)."""
+    return _Attention.apply(q, k, v, heads, float(scale))
+
+
 class FlatAdam:
     """torch.optim.Adam(params, lr, betas, eps, weight_decay) over the parameters of a `dist.FlatGrads`.
 

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as _dist
-from .linear import linear as _linear, causal_mlp as _causal_mlp
+from .linear import linear as _linear, causal_mlp as _causal_mlp, attention as _attention
 
 
 class EpisodeBatchNorm2d(nn.BatchNorm2d):
@@ -81,6 +81,8 @@ class MAB(nn.Module):
         super().__init__()
         if ln:
             raise NotImplementedError('the CMVAE hot path never enables layer norm')
+        if dim_V != 64 * num_heads or dim_Q != dim_K:
+            raise ValueError('the MI355X attention kernel needs heads of 64 channels and self-attention shapes')
         self.dim_V, self.num_heads = dim_V, num_heads
         self.fc_q = nn.Linear(dim_Q, dim_V)
         self.fc_k = nn.Linear(dim_K, dim_V)
@@ -88,17 +90,11 @@ class MAB(nn.Module):
         self.fc_o = nn.Linear(dim_V, dim_V)
 
     def forward(self, Q, K):
-        B, S, _ = Q.shape
-        hd = self.dim_V // self.num_heads
         q = _linear(Q, self.fc_q.weight, self.fc_q.bias)
         k = _linear(K, self.fc_k.weight, self.fc_k.bias)
         v = _linear(K, self.fc_v.weight, self.fc_v.bias)
-        # heads as a batch axis; same arithmetic as the reference's split/cat-on-batch form
-        qh = q.view(B, S, self.num_heads, hd).transpose(1, 2)
-        kh = k.view(B, -1, self.num_heads, hd).transpose(1, 2)
-        vh = v.view(B, -1, self.num_heads, hd).transpose(1, 2)
-        att = torch.softmax(qh.matmul(kh.transpose(-1, -2)) / math.sqrt(self.dim_V), -1)
-        o = (qh + att.matmul(vh)).transpose(1, 2).reshape(B, S, self.dim_V)
+        # heads are 64-column slices of the rows; softmax scale is 1/sqrt(dim_V) as in the reference
+        o = _attention(q, k, v, self.num_heads, 1.0 / math.sqrt(self.dim_V))
         return o + _linear(o, self.fc_o.weight, self.fc_o.bias, 'relu')
 
 

@@ -178,6 +178,15 @@ int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, const float* d
                      int in_f, int out_f, float* dX, int dx_pitch, float* dW, float* db,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ==== softmax attention core of the Set-Transformer MAB (omniglot/module.py:92-99), heads of 64 channels.
+ * Q, K, V, O, dO, dQ, dK, dV: [B, S, heads*64]; O = Q + softmax(scale * Q K^T) V per (episode, head);
+ * lse, delta: [B, heads, S] (log-sum-exp of the scaled scores, saved for the backward; scratch).  S <= 1024. */
+int cmvae_attention_fwd(const float* Q, const float* K, const float* V, int B, int S, int heads, float scale,
+                        float* O, float* lse, void* stream);
+int cmvae_attention_bwd(const float* Q, const float* K, const float* V, const float* lse, const float* dO,
+                        int B, int S, int heads, float scale, float* dQ, float* dK, float* dV, float* delta,
+                        void* stream);
+
 /* ==== NOTEARS-MLP causal layer on bulk rows (CausalEncoder.forward on [B*N,64], omniglot/module.py:165-188,
  * LocallyConnected :232-288).  hid [rows,2048] = elu(fc1(x)) comes from cmvae_linear_fwd(act=2);
  * eps[r][j] = x[r][j] - (sum_m hid[r][32j+m] w2[j][m] + b2[j]).

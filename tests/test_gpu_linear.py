@@ -101,3 +101,37 @@ def test_flat_adam_matches_torch_adam():
         opt_d.step()
     for r, d in zip(ref, dev):
         assert _rel(d, r) < 1e-6
+
+
+@pytest.mark.parametrize('B,S,heads', [(2, 5, 4), (3, 37, 4), (4, 300, 4), (1, 16, 1), (2, 600, 2)])
+def test_attention_core(B, S, heads):
+    """O = Q + softmax(QK^T * scale) V per head, forward and all three gradients (omniglot/module.py:92-99)."""
+    from cmvae_amd.linear import attention
+    g = torch.Generator().manual_seed(S)
+    C = 64 * heads
+    q, k, v, go = (torch.randn(B, S, C, generator=g) for _ in range(4))
+    scale = 1.0 / np.sqrt(C)
+
+    def ref(q, k, v):
+        qh, kh, vh = (t.view(B, S, heads, 64).transpose(1, 2) for t in (q, k, v))
+        att = torch.softmax(qh.matmul(kh.transpose(-1, -2)) * scale, -1)
+        return (qh + att.matmul(vh)).transpose(1, 2).reshape(B, S, C)
+
+    qr, kr, vr = (t.clone().double().requires_grad_(True) for t in (q, k, v))
+    orf = ref(qr, kr, vr)
+    orf.backward(go.double())
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    od = attention(qd, kd, vd, heads, scale)
+    od.backward(go.cuda())
+    assert _rel(od, orf) < 1e-5
+    for a, b in ((qd, qr), (kd, kr), (vd, vr)):
+        assert _rel(a.grad, b.grad) < 2e-5
+
+
+def test_attention_rejects_bad_shapes():
+    from cmvae_amd.linear import attention
+    with pytest.raises(RuntimeError):
+        attention(torch.randn(1, 4, 96).cuda(), torch.randn(1, 4, 96).cuda(), torch.randn(1, 4, 96).cuda(), 2, 0.1)
+    with pytest.raises(RuntimeError):
+        q = torch.randn(1, 2000, 64).cuda()
+        attention(q, q, q, 1, 0.1)
