@@ -1,0 +1,179 @@
+"""Trainer for the three CMVAE variants on MI355X: the reference's `Trainer(args)`, `.train()`,
+`.eval(shot, test)` (omniglot/trainer.py:18-240, mimgnet/trainer.py:18-197, celeba/trainer.py) around the
+HIP hot path.
+
+Kept: the loop structure (freq_iters training steps, then validation, best-checkpoint files holding
+{'state_dict', 'accuracy', 'epoch'} with the reference's state_dict keys, final test from the best
+checkpoints), Adam(lr, weight_decay), the loss `rec + kl + h_augment`, the acyclicity constants per variant,
+accuracy mean and 1.96*std/sqrt(n) confidence interval over `eval_episodes`.
+Changed: data lives on the GPU (cmvae_amd/data.py); losses are read back every
+`log_interval` steps instead of three device syncs per step; the final test loads the checkpoint that was
+actually written (the reference hard-codes '1shot_best_1000.pth' / 'best.pth'); episodes are sharded over
+ranks when launched with torch.distributed.run; TensorBoard / wandb are optional (a JSON-lines log is always
+written).
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dist as cdist
+from .data import EpisodeData, TrainStream
+from .linear import FlatAdam
+from .model import OmniglotGMVAE, FeatureGMVAE
+
+# (h_lambda, h_c, a_lambda) and the shots validated after every epoch, per variant
+# (omniglot/trainer.py:74,129-130; mimgnet/trainer.py:67,118; celeba/trainer.py:67,118)
+VARIANTS = {
+    'omniglot': dict(consts=(0.1, 0.1, 1e-4), val=[(1, False), (5, False)], final=[1, 5]),
+    'mimgnet': dict(consts=(0.1, 0.1, 1e-3), val=[(5, True)], final=[1, 5, 20, 50]),
+    'celeba': dict(consts=(1.0, 1.0, 1e-4), val=[(5, False)], final=[1, 5]),
+}
+
+
+class Trainer(object):
+    def __init__(self, args, variant='omniglot'):
+        self.args, self.variant = args, variant
+        self.rank, self.world = cdist.init_from_env()
+        self.device = torch.device(args.device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('cmvae_amd.Trainer needs a GPU device (there is no CPU path)')
+        self.data = EpisodeData(args.data_dir, variant, device=self.device,
+                                instances_per_class=getattr(args, 'instances_per_class', None))
+        if args.batch_size % self.world:
+            raise ValueError('batch size %d is not divisible by %d ranks' % (args.batch_size, self.world))
+        self.local_batch = args.batch_size // self.world
+        self.stream = TrainStream(self.data.train_pool(), args.batch_size * args.sample_size)
+        self.input_shape = self.data.input_shape
+        self.model = self._new_model()
+        self.flat = cdist.FlatGrads(self.model.parameters())
+        self.optimizer = FlatAdam(self.flat, lr=args.lr, weight_decay=args.weight_decay)
+        self.log_interval = max(1, int(getattr(args, 'log_interval', 50)))
+        self.best_files = {}
+        self.log_path = os.path.join(args.save_dir, 'train_log.jsonl')
+        os.makedirs(args.save_dir, exist_ok=True)
+
+    def _new_model(self):
+        a = self.args
+        kw = dict(unsupervised_em_iters=a.unsupervised_em_iters, semisupervised_em_iters=a.semisupervised_em_iters,
+                  fix_pi=a.fix_pi, component_size=a.way, latent_size=a.latent_size,
+                  train_mc_sample_size=a.train_mc_sample_size, test_mc_sample_size=a.test_mc_sample_size)
+        if self.variant == 'omniglot':
+            m = OmniglotGMVAE(input_shape=self.input_shape, hidden_size=a.hidden_size, **kw)
+        else:
+            m = FeatureGMVAE(input_shape=self.input_shape, linear=self.variant == 'mimgnet', **kw)
+        return m.to(self.device)
+
+    def _log(self, rec):
+        if self.rank == 0:
+            with open(self.log_path, 'a') as f:
+                f.write(json.dumps(rec) + '\n')
+
+    # ------------------------------------------------------------------ one training step
+    def train_step(self, h_lambda, h_c, a_lambda):
+        a = self.args
+        self.model.train()
+        self.flat.zero()
+        X = self.stream.next()                                         # the global meta-batch, same on every rank
+        shape = self.input_shape if isinstance(self.input_shape, list) else [self.input_shape]
+        X = X.view(a.batch_size, a.sample_size, *shape)[cdist.shard_slice(a.batch_size, self.rank, self.world)]
+        idx = cdist.draw_em_init(a.sample_size * a.train_mc_sample_size, a.way, a.batch_size, self.rank, self.world)
+        idx = torch.from_numpy(idx).to(self.device, non_blocking=True)
+        X_rec, rec_loss, kl_loss, h_augment, h = self.model(X, h_lambda, h_c, a_lambda, init_idx=idx)
+        (rec_loss + kl_loss + h_augment).backward()
+        self.flat.allreduce()
+        self.optimizer.step()
+        return rec_loss, kl_loss, h_augment, h
+
+    def train(self):
+        a, spec = self.args, VARIANTS[self.variant]
+        h_lambda, h_c, a_lambda = spec['consts']
+        global_epoch = global_step = 0
+        best = {shot: 0.0 for shot, _ in spec['val']}
+        while global_epoch * a.freq_iters < a.train_iters:
+            t0 = time.perf_counter()
+            steps = 0
+            for _ in range(a.freq_iters):
+                rec_loss, kl_loss, h_augment, h = self.train_step(h_lambda, h_c, a_lambda)
+                global_step += 1
+                steps += 1
+                if global_step % self.log_interval == 0 or a.debug:
+                    self._log({'step': global_step, 'rec': float(rec_loss.detach()), 'kld': float(kl_loss.detach()),
+                               'h_aug': float(h_augment.detach()), 'h': float(h.detach())})
+                if a.debug:
+                    break
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rec = {'epoch': global_epoch, 'step': global_step, 'train_episodes_per_s': a.batch_size * steps / dt,
+                   'h_lambda': h_lambda, 'h_c': h_c, 'lr': a.lr}
+            for shot, test in spec['val']:
+                mean, conf = self.eval(shot=shot, test=test)
+                rec['%dshot_acc' % shot], rec['%dshot_conf' % shot] = mean, conf
+                if best[shot] < mean:
+                    best[shot] = mean
+                    self.save_checkpoint(shot, mean, global_epoch, global_step)
+                if self.rank == 0:
+                    print('{0}shot {1}-th EPOCH Val Accuracy: {2:.4f}, BEST Accuracy: {3:.4f}'.format(
+                        shot, global_epoch, mean, best[shot]))
+            self._log(rec)
+            global_epoch += 1
+        return self.final_test()
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, shot, accuracy, epoch, step):
+        path = os.path.join(self.args.save_dir, '%dshot_best_%s.pth' % (shot, step))
+        if self.rank == 0:
+            torch.save({'state_dict': self.model.state_dict(), 'accuracy': accuracy, 'epoch': epoch,
+                        'optimizer': self.optimizer.state_dict()}, path)
+        self.best_files[shot] = path
+
+    def load_checkpoint(self, path, resume_optimizer=False):
+        state = torch.load(path, map_location=self.device, weights_only=True)
+        self.model = self._new_model()
+        self.model.load_state_dict(state['state_dict'])
+        self.flat = cdist.FlatGrads(self.model.parameters())
+        self.optimizer = FlatAdam(self.flat, lr=self.args.lr, weight_decay=self.args.weight_decay)
+        if resume_optimizer and 'optimizer' in state:
+            self.optimizer.load_state_dict(state['optimizer'])
+        return state
+
+    def final_test(self):
+        """Test accuracy of the best validation checkpoints (omniglot/trainer.py:179-216; mimgnet :144-174)."""
+        out = {}
+        spec = VARIANTS[self.variant]
+        if cdist.is_dist():
+            torch.distributed.barrier()
+        for shot in spec['final']:
+            src = self.best_files.get(shot) or self.best_files.get(5) or self.best_files.get(1)
+            if src is not None:
+                self.load_checkpoint(src)
+            mean, conf = self.eval(shot=shot, test=True)
+            out[shot] = (mean, conf)
+            if self.rank == 0:
+                print('{0}shot Final Test Accuracy: {1:.4f} Confidence Interval: {2:.4f}'.format(shot, mean, conf))
+        self._log({'final_test': {str(k): v for k, v in out.items()}})
+        return out
+
+    # ------------------------------------------------------------------ evaluation
+    def eval(self, shot, test=False):
+        """Mean accuracy and 95 % interval over `eval_episodes` test episodes.  Episodes are drawn from the single
+        host numpy stream in batches of `batch_size` and dealt contiguously to the ranks; only the per-episode
+        accuracies are gathered."""
+        a = self.args
+        self.model.eval()
+        accs = []
+        sl = cdist.shard_slice(a.batch_size, self.rank, self.world)
+        for _ in range(max(1, a.eval_episodes // a.batch_size)):
+            X_tr, y_tr, X_te, y_te = self.data.generate_test_episode(way=a.way, shot=shot, query=a.query,
+                                                                     n_episodes=a.batch_size, test=test)
+            y_pred = self.model.prediction(X_tr[sl].contiguous(), y_tr[sl].contiguous(), X_te[sl].contiguous())
+            accs.append(torch.eq(y_pred, y_te[sl]).float().mean(-1))
+        acc = torch.cat(accs)                                          # one device->host copy per eval
+        if self.world > 1:
+            parts = [torch.empty_like(acc) for _ in range(self.world)]
+            torch.distributed.all_gather(parts, acc)
+            acc = torch.stack([p.view(-1, self.local_batch) for p in parts], 1).reshape(-1)
+        acc = acc.cpu().numpy().astype(np.float64)[:a.eval_episodes]
+        return float(np.mean(acc)), float(1.96 * np.std(acc) / np.sqrt(a.eval_episodes))
