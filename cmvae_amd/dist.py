@@ -59,6 +59,17 @@ def draw_em_init(n_samples, k, b_global, r=None, ws=None):
     return idx[shard_slice(b_global, r, ws)].astype(np.int64)
 
 
+def gather_episode_values(values, local_batch):
+    """Per-episode values [n_calls * local_batch] of every rank -> one vector in global episode order
+    (call t holds the episodes t*B_g ... (t+1)*B_g - 1, rank r owns the r-th contiguous slice of them).
+    The only collective of the evaluation loop."""
+    if world_size() == 1:
+        return values
+    parts = [torch.empty_like(values) for _ in range(world_size())]
+    tdist.all_gather(parts, values.contiguous())
+    return torch.stack([p.view(-1, local_batch) for p in parts], 1).reshape(-1)
+
+
 class FlatGrads:
     """All parameter gradients as views into one flat fp32 buffer (4.56 MB for Omniglot), so the
     step's gradient exchange is a single all-reduce with no pack/unpack copies."""

@@ -171,9 +171,6 @@ class Trainer(object):
             y_pred = self.model.prediction(X_tr[sl].contiguous(), y_tr[sl].contiguous(), X_te[sl].contiguous())
             accs.append(torch.eq(y_pred, y_te[sl]).float().mean(-1))
         acc = torch.cat(accs)                                          # one device->host copy per eval
-        if self.world > 1:
-            parts = [torch.empty_like(acc) for _ in range(self.world)]
-            torch.distributed.all_gather(parts, acc)
-            acc = torch.stack([p.view(-1, self.local_batch) for p in parts], 1).reshape(-1)
+        acc = cdist.gather_episode_values(acc, self.local_batch)
         acc = acc.cpu().numpy().astype(np.float64)[:a.eval_episodes]
         return float(np.mean(acc)), float(1.96 * np.std(acc) / np.sqrt(a.eval_episodes))

@@ -51,6 +51,10 @@ def _worker(rank, world, port, out):
     flat.allreduce()
     np.random.seed(77)
     idx = cdist.draw_em_init(50, 3, 8)
+    # evaluation: 3 calls of a global batch of 4 episodes, 2 per rank; value = global episode number
+    mine = torch.tensor([4.0 * t + 2 * rank + j for t in range(3) for j in range(2)])
+    gathered = cdist.gather_episode_values(mine, 2)
+    assert gathered.tolist() == [float(i) for i in range(12)], gathered
     out[rank] = dict(y=y.detach(), grad=flat.flat.clone(), rm=net[1].running_mean.clone(),
                      rv=net[4].running_var.clone(), idx=idx, after=np.random.rand())
     torch.distributed.barrier()
