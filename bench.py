@@ -90,6 +90,22 @@ def useful_flops(g, ncb):
     return 2.0 * 64 * 64 * taps * n_img * ncb
 
 
+def pmc_traffic_conv_gemm():
+    """HBM bytes per launch of the conv launches of conv_gemm_kernel (template argument LINEAR = false), from the
+    newest committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes over this
+    same workload, gfx950 correction applied).  PMC counters cannot be read from inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None, None
+    ks = json.load(open(files[-1]))['kernels']
+    sel = [v for k, v in ks.items() if k.startswith('conv_gemm_kernel') and k.rstrip().endswith('false>')]
+    n = sum(v['launches'] for v in sel)
+    if not n:
+        return None, None
+    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / n, os.path.basename(files[-1])
+
+
 def roofline_conv_gemm(step_fn):
     """Dominant kernel of the step: conv_gemm_kernel (fp32 MFMA gather-GEMM: all decoder / encoder convs and
     their data gradients).  Every launch of one extra, untimed training step is bracketed by HIP events on
@@ -117,9 +133,12 @@ def roofline_conv_gemm(step_fn):
     total_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
     total_flops = sum(f for _, _, f in rec)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
-    return {'kernel': 'conv_gemm_kernel', 'bound': 'mfma', 'achieved': round(achieved, 2),
+    traffic, src = pmc_traffic_conv_gemm()
+    return {'kernel': 'conv_gemm_kernel (conv / conv-transpose / data-gradient launches)', 'bound': 'mfma',
+            'achieved': round(achieved, 2),
             'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-            'traffic': None, 'launches_per_step': len(rec), 'avg_launch_us': round(total_ms * 1e3 / len(rec), 1),
+            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': src,
+            'launches_per_step': len(rec), 'avg_launch_us': round(total_ms * 1e3 / len(rec), 1),
             'algorithmic_gflop_per_launch': round(total_flops / len(rec) / 1e9, 2),
             'share_of_step_ms': round(total_ms, 2)}
 

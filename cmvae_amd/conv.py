@@ -65,10 +65,15 @@ def geom_convT_phase(n, Hi, Wi, k, py, px, C=64):
 
 
 def geom_convT_dgrad(n, Hi, Wi, k, C=64):
-    """Data gradient of the transposed conv = stride-2 conv over d_out [n,Ho,Wo,C] -> [n,Hi,Wi,C]."""
+    """Data gradient of the transposed conv = stride-2 conv over d_out [n,Ho,Wo,C] -> [n,Hi,Wi,C].
+    Returns (geometry, order): tap t of the geometry is kernel tap order[t] = ky*k + kx."""
     Ho, Wo = convT_out(Hi, k), convT_out(Wi, k)
-    taps = [(ky - 1, kx - 1) for ky in range(k) for kx in range(k)]
-    return _geom(n * Hi * Wi, Hi, Wi, Ho, Wo, 2, 2, Hi, Wi, 1, 1, 0, 0, taps, C, C, C, C * C)
+    # taps kx and kx+2 of one kernel row read the same d_out pixels one output column apart: running them
+    # back to back turns half of the operand re-reads into L2 hits
+    kxs = [kx for par in (0, 1) for kx in range(par, k, 2)]
+    order = [ky * k + kx for ky in range(k) for kx in kxs]
+    taps = [(t // k - 1, t % k - 1) for t in order]
+    return _geom(n * Hi * Wi, Hi, Wi, Ho, Wo, 2, 2, Hi, Wi, 1, 1, 0, 0, taps, C, C, C, C * C), order
 
 
 def geom_linear(rows, K, N, a_pitch=None, o_pitch=None):

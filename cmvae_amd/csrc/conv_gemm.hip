@@ -132,7 +132,7 @@ __device__ __forceinline__ float apply_act(float v) {
 // ---------------------------------------------------------------------------- forward gather-GEMM
 // One software pipeline over the block's (tile, tap) steps: while the MFMAs of step s run out of LDS, the
 // operands of step s+1 (possibly the first tap of the block's next tile) are already in flight to registers.
-template <int ACT, bool HAS_T>
+template <int ACT, bool HAS_T, bool LINEAR>
 __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const float* __restrict__ A,
                                                            const float* __restrict__ Wt,
                                                            const float* __restrict__ bias,
@@ -160,10 +160,24 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
     bool ok[8];
     int ltile = blockIdx.x;          // tile whose operands are being loaded
     int par = 0;                     // opix buffer of the tile being multiplied
-    dec.decode<8>(ltile * BM + rb, 16, [&](int e, int n, int y, int x) {
-        ri[e] = make_row(g, ltile * BM + rb + 16 * e, n, y, x);
-    });
-    if (tid < BM) opix[0][tid] = out_pixel(g, ltile * BM + tid);
+    auto rows_of_tile = [&](int tile, int* op) {
+        if (LINEAR) {        // one row per "image": no (y, x) to decode (nn.Linear launches, own kernel symbol)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = tile * BM + rb + 16 * e;
+                ri[e].off = r * g.a_pitch;
+                ri[e].ys = r < g.rows_total ? 0 : INVALID_YS;
+                ri[e].xs = 0;
+            }
+            if (tid < BM) op[tid] = tile * BM + tid < g.rows_total ? tile * BM + tid : -1;
+        } else {
+            dec.decode<8>(tile * BM + rb, 16, [&](int e, int n, int y, int x) {
+                ri[e] = make_row(g, tile * BM + rb + 16 * e, n, y, x);
+            });
+            if (tid < BM) op[tid] = out_pixel(g, tile * BM + tid);
+        }
+    };
+    rows_of_tile(ltile, opix[0]);
 #pragma unroll
     for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], 0, q, &ok[e]);
     rw0 = *reinterpret_cast<const float4*>(Wn);
@@ -193,10 +207,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
         if (tn == g.ntaps) {
             tn = 0;
             ltile += gridDim.x;
-            dec.decode<8>(ltile * BM + rb, 16, [&](int e, int n, int y, int x) {
-                ri[e] = make_row(g, ltile * BM + rb + 16 * e, n, y, x);
-            });
-            if (tid < BM) opix[par ^ 1][tid] = out_pixel(g, ltile * BM + tid);
+            rows_of_tile(ltile, opix[par ^ 1]);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tn, q, &ok[e]);
@@ -469,10 +480,10 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     hipStream_t st = (hipStream_t)stream;
 #define CMVAE_LAUNCH_GEMM(ACT)                                                                                  \
     if (a_scale)                                                                                                \
-        hipLaunchKernelGGL((conv_gemm_kernel<ACT, true>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale,      \
+        hipLaunchKernelGGL((conv_gemm_kernel<ACT, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, \
                            a_shift, out, stats_part);                                                           \
     else                                                                                                        \
-        hipLaunchKernelGGL((conv_gemm_kernel<ACT, false>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale,     \
+        hipLaunchKernelGGL((conv_gemm_kernel<ACT, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, \
                            a_shift, out, stats_part)
     switch (act) {
         case 0: CMVAE_LAUNCH_GEMM(0); break;
@@ -563,9 +574,9 @@ static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const
     const float* nul = nullptr;
     float* nostats = nullptr;
     switch (act) {
-        case 0: hipLaunchKernelGGL((conv_gemm_kernel<0, false>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
-        case 1: hipLaunchKernelGGL((conv_gemm_kernel<1, false>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
-        default: hipLaunchKernelGGL((conv_gemm_kernel<2, false>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
+        case 0: hipLaunchKernelGGL((conv_gemm_kernel<0, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
+        case 1: hipLaunchKernelGGL((conv_gemm_kernel<1, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
+        default: hipLaunchKernelGGL((conv_gemm_kernel<2, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
     }
     return check_launch("conv_gemm_kernel (linear)");
 }

@@ -171,9 +171,10 @@ class _DecoderBCE(torch.autograd.Function):
                                     accumulate_db=not first, a_scale=sc, a_shift=sh)
                     first = False
             grads_w[li], grads_b[li] = dW, db
-            wtd = ws[li].detach().permute(2, 3, 0, 1).reshape(k * k, 64, 64).contiguous()   # [tap][ci][co]
+            gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k)
+            wtd = ws[li].detach().permute(2, 3, 0, 1).reshape(k * k, 64, 64)[order].contiguous()   # [tap][ci][co]
             d_in = torch.empty(n * Hi * Hi, 64, device=dev)
-            conv.conv_gemm(conv.geom_convT_dgrad(n, Hi, Hi, k), dy, wtd, d_in)
+            conv.conv_gemm(gd, dy, wtd, d_in)
             d = d_in
             if li > 0:
                 sums = bn_relu_bwd_sums(d, x_in, fold_in, masked=False)

@@ -90,9 +90,10 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k):
     assert rel_err(dW, w.grad) < TOL
     assert rel_err(db, b.grad) < TOL
     # data gradient wrt a (the post-activation input)
-    wtd = w.detach().permute(2, 3, 0, 1).contiguous().to(device)      # [tap][ci][co]
+    gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k)
+    wtd = w.detach().permute(2, 3, 0, 1).reshape(k * k, 64, 64)[order].contiguous().to(device)      # [tap][ci][co]
     da = torch.empty(n * Hi * Hi, 64, device=device)
-    conv.conv_gemm(conv.geom_convT_dgrad(n, Hi, Hi, k), gyd, wtd, da)
+    conv.conv_gemm(gd, gyd, wtd, da)
     assert rel_err(from_nhwc(da.cpu(), n, Hi, Hi), a.grad) < TOL
 
 
