@@ -145,8 +145,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
 // ------------------------------------------------------------------ last decoder layer, forward
 // y3 [n,14,14,64] --relu(bn3)--> convT(64->1,k4,s2,p1) + b --sigmoid--> p [n,28,28];
 // loss_part[img] = -sum_pix ( x*max(log p,-100) + (1-x)*max(log1p(-p),-100) ),  x = target[img / M]
+//
+// Per image: Y[pix][tap] = a3[pix][0:64] . w4[0:64][tap] on v_mfma_f32_16x16x4_f32 (16 pixels x 16 taps per
+// accumulator, 13 row blocks per image), then every output pixel gathers its <= 4 (pixel, tap) terms from LDS.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int HI = 14, HO = 28, NPIX_I = HI * HI, NPIX_O = HO * HO;
-constexpr int AL = 68;
+constexpr int AL = 68;                 // pitch of the activation tile: conflict-free b128 fragment reads
+constexpr int RB = (NPIX_I + 15) / 16;  // 13 blocks of 16 pixels (12 padded rows)
+constexpr int YP = 20;                 // pitch of Y: 4*YP = 16 (mod 64) makes the accumulator stores conflict-free
 
 __global__ __launch_bounds__(256) void dec_out_fwd_kernel(const float* __restrict__ y3,
                                                           const float* __restrict__ scale,
@@ -155,69 +161,90 @@ __global__ __launch_bounds__(256) void dec_out_fwd_kernel(const float* __restric
                                                           const float* __restrict__ b4,
                                                           const float* __restrict__ target, int M, int nimg,
                                                           float* __restrict__ p_out, float* __restrict__ loss_part) {
-    __shared__ __align__(16) float as[NPIX_I * AL];
-    __shared__ __align__(16) float ws[16 * C];     // [tap][ci]
+    __shared__ __align__(16) float as[RB * 16 * AL];
+    __shared__ float ys[RB * 16 * YP];
     __shared__ float lred[4];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 16 * C; e += 256) ws[e] = w4[(e & 63) * 16 + (e >> 6)];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    // B fragments: MFMA (t, j) contracts channel 16t + 4g + j on lane group g (A reads a float4 at that offset)
+    float bw[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bw[4 * t + j] = w4[(16 * t + 4 * g + j) * 16 + i];
     const int q = tid & 15;
     const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
     const float bias = b4[0];
+    for (int e = tid; e < (RB * 16 - NPIX_I) * AL; e += 256) as[NPIX_I * AL + e] = 0.f;
+    // the image's 196 x 16 float4 are held in registers one image ahead, so HBM latency hides under the MFMA and
+    // gather phases of the current image
+    constexpr int NLD = (NPIX_I * 16 + 255) / 256;       // 13 float4 per thread (the last one on 64 threads only)
+    float4 pre[NLD];
+    auto fetch = [&](int img) {
+        const float4* yi = reinterpret_cast<const float4*>(y3 + (long)img * NPIX_I * C);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + 256 * k;
+            pre[k] = yi[e < NPIX_I * 16 ? e : 0];
+        }
+    };
+    if ((int)blockIdx.x < nimg) fetch(blockIdx.x);
     for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
         __syncthreads();
-        const float* yi = y3 + (long)img * NPIX_I * C;
-        for (int e = tid; e < NPIX_I * 16; e += 256) {
-            const int pix = e >> 4;
-            float4 v = reinterpret_cast<const float4*>(yi + pix * C)[q];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + 256 * k;
+            float4 v = pre[k];
             v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
             v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
             v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
             v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-            *reinterpret_cast<float4*>(&as[pix * AL + 4 * q]) = v;
+            if (e < NPIX_I * 16) *reinterpret_cast<float4*>(&as[(e >> 4) * AL + 4 * q]) = v;
+        }
+        __syncthreads();
+        if (img + (int)gridDim.x < nimg) fetch(img + gridDim.x);
+        for (int rbk = w; rbk < RB; rbk += 4) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* ap = &as[(16 * rbk + i) * AL + 4 * g];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * t);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bw[4 * t + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bw[4 * t + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bw[4 * t + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bw[4 * t + 3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ys[(16 * rbk + 4 * g + reg) * YP + i] = acc[reg];   // row 4g+reg, tap i
         }
         __syncthreads();
         const float* tg = target + (long)(img / M) * NPIX_O;
         float lsum = 0.f;
-        if (tid < NPIX_I) {
-            const int m = tid / HI, l = tid - m * HI;
+        for (int o = tid; o < NPIX_O; o += 256) {
+            const int oy = o / HO, ox = o - oy * HO;
+            // output row oy takes kernel row ky = oy + 1 - 2*iy from input row iy: two candidates
+            const int iy0 = (oy + 1) >> 1, ky0 = oy + 1 - 2 * iy0;
+            const int ix0 = (ox + 1) >> 1, kx0 = ox + 1 - 2 * ix0;
+            float acc = bias;
 #pragma unroll
-            for (int ph = 0; ph < 4; ++ph) {
-                const int py = ph >> 1, px = ph & 1;
-                float acc = bias;
+            for (int a = 0; a < 2; ++a) {
+                const int iy = iy0 - a, ky = ky0 + 2 * a;
+                if (iy < 0 || iy >= HI) continue;
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    // py=0: ky in {1,3}, dy in {0,-1};  py=1: ky in {0,2}, dy in {1,0}
-                    const int ky = py ? 2 * a : 2 * a + 1;
-                    const int iy = m + (py ? 1 - a : -a);
-                    if (iy < 0 || iy >= HI) continue;
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int kx = px ? 2 * b : 2 * b + 1;
-                        const int ix = l + (px ? 1 - b : -b);
-                        if (ix < 0 || ix >= HI) continue;
-                        const float* ap = &as[(iy * HI + ix) * AL];
-                        const float* wp = &ws[(ky * 4 + kx) * C];
-#pragma unroll
-                        for (int c4 = 0; c4 < 16; ++c4) {
-                            const float4 av = *reinterpret_cast<const float4*>(ap + 4 * c4);
-                            const float4 wv = *reinterpret_cast<const float4*>(wp + 4 * c4);
-                            acc = fmaf(av.x, wv.x, acc);
-                            acc = fmaf(av.y, wv.y, acc);
-                            acc = fmaf(av.z, wv.z, acc);
-                            acc = fmaf(av.w, wv.w, acc);
-                        }
-                    }
+                for (int b = 0; b < 2; ++b) {
+                    const int ix = ix0 - b, kx = kx0 + 2 * b;
+                    if (ix < 0 || ix >= HI) continue;
+                    acc += ys[(iy * HI + ix) * YP + ky * 4 + kx];
                 }
-                const int o = (2 * m + py) * HO + 2 * l + px;
-                const float p = 1.f / (1.f + expf(-acc));
-                p_out[(long)img * NPIX_O + o] = p;
-                const float x = tg[o];
-                lsum -= x * fmaxf(logf(p), -100.f) + (1.f - x) * fmaxf(log1pf(-p), -100.f);
             }
+            const float p = 1.f / (1.f + expf(-acc));
+            p_out[(long)img * NPIX_O + o] = p;
+            const float x = tg[o];
+            lsum -= x * fmaxf(logf(p), -100.f) + (1.f - x) * fmaxf(log1pf(-p), -100.f);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
-        if ((tid & 63) == 0) lred[tid >> 6] = lsum;
+        if (lane == 0) lred[w] = lsum;
         __syncthreads();
         if (tid == 0) loss_part[img] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
     }
@@ -227,7 +254,14 @@ __global__ __launch_bounds__(256) void dec_out_fwd_kernel(const float* __restric
 // dlogit = gscale * (p - x) * p(1-p) / max(p(1-p), 1e-12)      (BCELoss backward through the sigmoid)
 // dybn3[pix][ci] = mask * sum_tap dlogit[tap pos] * w4[ci][tap]     (mask: relu(bn3(y3)) > 0)
 // part[blk] = { dW4[64][16], sum dybn3[64], sum dybn3*xhat[64], db4 }            (L = 1024 + 128 + 1)
+//
+// Both contractions run on v_mfma_f32_16x16x4_f32, one wave per block of 16 input pixels:
+//   G[pix][ci] = D[pix][tap] . w4^T[tap][ci]        D gathered from the zero-padded dlogit image in LDS
+//   dW4[ci][tap] += a3^T[ci][pix] . D[pix][tap]     a3 = relu(bn3(y3)), staged per wave in LDS
+// G goes through a per-wave LDS tile so that y3 is read and dybn3 written as full 256-B rows.
 constexpr int DEC_BWD_L = 64 * 16 + 128 + 1;
+constexpr int GP = 68;                 // G staging pitch: accumulator-layout stores conflict-free
+constexpr int SP = 80;                 // a3 staging pitch: A-fragment (pixel-major) reads conflict-free
 
 __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restrict__ y3,
                                                           const float* __restrict__ scale,
@@ -240,71 +274,157 @@ __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restric
                                                           const float* __restrict__ g_dev, float gmul,
                                                           float* __restrict__ dybn, float* __restrict__ part) {
     const float gscale = gmul * (g_dev ? g_dev[0] : 1.f);
-    __shared__ float dl[(HO + 2) * (HO + 2)];     // zero-padded border: taps never branch
-    __shared__ float red[4 * (16 + 2) * 64];
+    constexpr int PL = HO + 2;                     // zero-padded border: taps never branch
+    __shared__ float dl[2][PL * PL];
+    __shared__ __align__(16) float gst[4][16 * GP];
+    __shared__ __align__(16) float ast[4][16 * SP];
     __shared__ float dbred[4];
-    const int tid = threadIdx.x, ci = tid & 63, w = tid >> 6;
-    constexpr int PL = HO + 2;
-    float wreg[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    float bw[16];                                  // w4[ci = 16cb + i][tap = 4s + g]
 #pragma unroll
-    for (int t = 0; t < 16; ++t) wreg[t] = w4[ci * 16 + t];
-    const float sc = scale[ci], sh = shift[ci], mu = mean[ci], is = invstd[ci];
-    float dw[16];
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) dw[t] = 0.f;
-    float s1 = 0.f, s2 = 0.f, dbs = 0.f;
-    for (int e = tid; e < PL * PL; e += 256) dl[e] = 0.f;
-    for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
-        __syncthreads();
+        for (int s4 = 0; s4 < 4; ++s4) bw[4 * cb + s4] = w4[(16 * cb + i) * 16 + 4 * s4 + g];
+    // row pass: lane = (row g + 4j, channels 4i .. 4i+3)
+    const float4 sc = reinterpret_cast<const float4*>(scale)[i], sh = reinterpret_cast<const float4*>(shift)[i];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[i], is = reinterpret_cast<const float4*>(invstd)[i];
+    floatx4 dw[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) dw[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float dbs = 0.f;
+    for (int e = tid; e < 2 * PL * PL; e += 256) (&dl[0][0])[e] = 0.f;
+    __syncthreads();
+    int buf = 0;
+    float* gw = gst[w];
+    float* aw = ast[w];
+    // operands are fetched one step ahead: p / target of the next image, y3 rows of the wave's next pixel block
+    constexpr int NPT = (NPIX_O + 255) / 256;
+    float pp[NPT], tt[NPT];
+    float4 vv[4];
+    auto fetch_pt = [&](int img) {
         const float* tg = target + (long)(img / M) * NPIX_O;
-        for (int o = tid; o < NPIX_O; o += 256) {
-            const float p = p_in[(long)img * NPIX_O + o];
-            const float x = tg[o];
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int o = tid + 256 * k, oo = o < NPIX_O ? o : 0;
+            pp[k] = p_in[(long)img * NPIX_O + oo];
+            tt[k] = tg[oo];
+        }
+    };
+    auto fetch_rows = [&](int img, int rbk) {
+        const float* yi = y3 + (long)img * NPIX_I * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int px = 16 * rbk + g + 4 * j;
+            vv[j] = *reinterpret_cast<const float4*>(yi + (px < NPIX_I ? px : NPIX_I - 1) * C + 4 * i);
+        }
+    };
+    if ((int)blockIdx.x < nimg) {
+        fetch_pt(blockIdx.x);
+        fetch_rows(blockIdx.x, w);
+    }
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x, buf ^= 1) {
+        float* dlb = dl[buf];
+        const bool more = img + (int)gridDim.x < nimg;
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int o = tid + 256 * k;
+            const float p = pp[k], x = tt[k];
             const float pq = p * (1.f - p);
             const float d = gscale * (p - x) * pq / fmaxf(pq, 1e-12f);
-            dl[(o / HO + 1) * PL + (o % HO) + 1] = d;
-            dbs += d;
+            const int oy = o / HO;
+            if (o < NPIX_O) {
+                dlb[(oy + 1) * PL + (o - oy * HO) + 1] = d;
+                dbs += d;
+            }
         }
-        __syncthreads();
-        const float* yi = y3 + (long)img * NPIX_I * C;
+        if (more) fetch_pt(img + gridDim.x);
+        __syncthreads();          // the only block barrier per image (dl is double-buffered)
         float* di = dybn + (long)img * NPIX_I * C;
-        for (int pix = w; pix < NPIX_I; pix += 4) {
-            const int iy = pix / HI, ix = pix - iy * HI;
-            const float v = yi[pix * C + ci];
-            const float a = fmaxf(fmaf(v, sc, sh), 0.f);
-            // output positions (2iy-1+ky, 2ix-1+kx) -> padded index (2iy+ky, 2ix+kx)
-            const float* dp = &dl[(2 * iy) * PL + 2 * ix];
-            float acc = 0.f;
+        for (int rbk = w; rbk < RB; rbk += 4) {
+            float4 vr[4];
 #pragma unroll
-            for (int ky = 0; ky < 4; ++ky)
+            for (int j = 0; j < 4; ++j) vr[j] = vv[j];
+            if (rbk + 4 < RB) fetch_rows(img, rbk + 4);
+            else if (more) fetch_rows(img + gridDim.x, w);
+            // ---- G = D . w4^T
+            {
+                const int px = 16 * rbk + i;
+                const bool ok = px < NPIX_I;
+                const int iy = px / HI, ix = px - iy * HI;
+                const float* dp = dlb + (ok ? (2 * iy) * PL + 2 * ix + g : 0);      // tap (ky = s, kx = g)
+                floatx4 G[4];
 #pragma unroll
-                for (int kx = 0; kx < 4; ++kx) {
-                    const float d = dp[ky * PL + kx];
-                    acc = fmaf(d, wreg[ky * 4 + kx], acc);
-                    dw[ky * 4 + kx] = fmaf(a, d, dw[ky * 4 + kx]);
+                for (int cb = 0; cb < 4; ++cb) G[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    float a = dp[s4 * PL];
+                    a = ok ? a : 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        G[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[4 * cb + s4], G[cb], 0, 0, 0);
                 }
-            const float g = a > 0.f ? acc : 0.f;
-            di[pix * C + ci] = g;
-            s1 += g;
-            s2 = fmaf(g, (v - mu) * is, s2);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) gw[(4 * g + reg) * GP + 16 * cb + i] = G[cb][reg];
+            }
+            // ---- rows: mask, dybn3, BatchNorm-backward sums, a3 for the weight gradient
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = g + 4 * j, px = 16 * rbk + rr;
+                const bool ok = px < NPIX_I;
+                const float4 gv = *reinterpret_cast<const float4*>(&gw[rr * GP + 4 * i]);
+                const float4 v = vr[j];
+                float4 a, o;
+                a.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                a.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+                if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                o.x = a.x > 0.f ? gv.x : 0.f; o.y = a.y > 0.f ? gv.y : 0.f;
+                o.z = a.z > 0.f ? gv.z : 0.f; o.w = a.w > 0.f ? gv.w : 0.f;
+                if (ok) *reinterpret_cast<float4*>(di + px * C + 4 * i) = o;
+                s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
+                s2.x = fmaf(o.x, (v.x - mu.x) * is.x, s2.x); s2.y = fmaf(o.y, (v.y - mu.y) * is.y, s2.y);
+                s2.z = fmaf(o.z, (v.z - mu.z) * is.z, s2.z); s2.w = fmaf(o.w, (v.w - mu.w) * is.w, s2.w);
+                *reinterpret_cast<float4*>(&aw[rr * SP + 4 * i]) = a;
+            }
+            // ---- dW4 += a3^T . D   (contraction over the 16 pixels: 4 k-steps of 4)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int px = 16 * rbk + 4 * s4 + g;
+                const bool ok = px < NPIX_I;
+                const int iy = px / HI, ix = px - iy * HI;
+                float b = dlb[ok ? (2 * iy + (i >> 2)) * PL + 2 * ix + (i & 3) : 0];   // tap i = ky*4 + kx
+                b = ok ? b : 0.f;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    dw[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[(4 * s4 + g) * SP + 16 * cb + i], b, dw[cb], 0, 0, 0);
+            }
         }
     }
+    // ---- block partials (fixed order): dW4, BatchNorm sums, db4
     __syncthreads();
+    float* red = &gst[0][0];                       // 4 waves x 1024 floats = 16 KB <= sizeof(gst)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) red[(w * 18 + t) * 64 + ci] = dw[t];
-    red[(w * 18 + 16) * 64 + ci] = s1;
-    red[(w * 18 + 17) * 64 + ci] = s2;
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) red[w * 1024 + (16 * cb + 4 * g + reg) * 16 + i] = dw[cb][reg];
+    float* red2 = &ast[0][0];                      // [2][4 waves][4 row groups][64]
+    *reinterpret_cast<float4*>(&red2[((0 * 4 + w) * 4 + g) * 64 + 4 * i]) = s1;
+    *reinterpret_cast<float4*>(&red2[((1 * 4 + w) * 4 + g) * 64 + 4 * i]) = s2;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dbs += __shfl_xor(dbs, o);
-    if (ci == 0) dbred[w] = dbs;
+    if (lane == 0) dbred[w] = dbs;
     __syncthreads();
     float* pb = part + (long)blockIdx.x * DEC_BWD_L;
-    for (int e = tid; e < 18 * 64; e += 256) {
-        const int t = e >> 6, c = e & 63;
-        const float s = (red[(0 * 18 + t) * 64 + c] + red[(1 * 18 + t) * 64 + c]) +
-                        (red[(2 * 18 + t) * 64 + c] + red[(3 * 18 + t) * 64 + c]);
-        if (t < 16) pb[c * 16 + t] = s;            // dW4[ci][tap]
-        else pb[1024 + (t - 16) * 64 + c] = s;     // BN-backward sums
+    for (int e = tid; e < 1024; e += 256) pb[e] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+    if (tid < 128) {
+        const int k = tid >> 6, c = tid & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red2[(k * 16 + r) * 64 + c];
+        pb[1024 + k * 64 + c] = s;
     }
     if (tid == 0) pb[1024 + 128] = (dbred[0] + dbred[1]) + (dbred[2] + dbred[3]);
 }
