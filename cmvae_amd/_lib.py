@@ -27,8 +27,9 @@ class ConvGeom(ctypes.Structure):
     """struct cmvae_conv_geom (include/cmvae_abi.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in ('rows_total', 'Hg', 'Wg', 'Hi', 'Wi', 'sy', 'sx', 'Ho', 'Wo', 'oys',
                                               'oxs', 'oy0', 'ox0', 'ntaps', 'a_pitch', 'o_pitch', 'w_pitch')] + \
-               [('w_tap_stride', ctypes.c_int64), ('w_nblk_stride', ctypes.c_int64),
-                ('dy', ctypes.c_int32 * 32), ('dx', ctypes.c_int32 * 32), ('a_col', ctypes.c_int32 * 32)]
+               [('w_nblk_stride', ctypes.c_int64),
+                ('dy', ctypes.c_int32 * 32), ('dx', ctypes.c_int32 * 32), ('a_col', ctypes.c_int32 * 32),
+                ('w_off', ctypes.c_int32 * 32)]
 
 
 _PG = ctypes.POINTER(ConvGeom)

@@ -5,6 +5,7 @@ nn.Linear, plus thin wrappers over cmvae_conv_gemm / cmvae_conv_wgrad.
 All activations are channels-last matrices [pixels, C] (C = 64 in the conv stacks).
 """
 import ctypes
+import functools
 
 import torch
 
@@ -18,19 +19,22 @@ def _stream():
 
 
 def _geom(rows, Hg, Wg, Hi, Wi, sy, sx, Ho, Wo, oys, oxs, oy0, ox0, taps, a_pitch, o_pitch, w_pitch, w_tap_stride,
-          w_nblk_stride=0, a_cols=None):
+          w_nblk_stride=0, a_cols=None, w_taps=None):
+    """w_taps: index of each tap's 64x64 block in the weight tensor (default 0..ntaps-1)."""
     g = ConvGeom()
     g.rows_total, g.Hg, g.Wg, g.Hi, g.Wi, g.sy, g.sx = rows, Hg, Wg, Hi, Wi, sy, sx
     g.Ho, g.Wo, g.oys, g.oxs, g.oy0, g.ox0 = Ho, Wo, oys, oxs, oy0, ox0
     g.ntaps = len(taps)
     g.a_pitch, g.o_pitch, g.w_pitch = a_pitch, o_pitch, w_pitch
-    g.w_tap_stride, g.w_nblk_stride = w_tap_stride, w_nblk_stride
+    g.w_nblk_stride = w_nblk_stride
     for t, (dy, dx) in enumerate(taps):
         g.dy[t], g.dx[t] = dy, dx
         g.a_col[t] = 0 if a_cols is None else a_cols[t]
+        g.w_off[t] = (t if w_taps is None else w_taps[t]) * w_tap_stride
     return g
 
 
+@functools.lru_cache(maxsize=None)
 def geom_conv3x3(n, H, W, transpose=False, C=64):
     """3x3 / stride 1 / pad 1 conv over [n,H,W,C]; transpose=True gives the data-gradient taps."""
     taps = [((1 - ky) if transpose else (ky - 1), (1 - kx) if transpose else (kx - 1))
@@ -55,27 +59,35 @@ def convT_phase_taps(k, py, px):
     return out
 
 
+@functools.lru_cache(maxsize=None)
 def geom_convT_phase(n, Hi, Wi, k, py, px, C=64):
-    """One sub-pixel phase of ConvTranspose2d(k, stride 2, pad 1): [n,Hi,Wi,C] -> [n,Ho,Wo,C]."""
+    """One sub-pixel phase of ConvTranspose2d(k, stride 2, pad 1): [n,Hi,Wi,C] -> [n,Ho,Wo,C].
+    Returns (geometry, tap_idx): the geometry's weight offsets address the FULL kernel [k*k][co][ci], tap t of
+    the phase being kernel tap tap_idx[t] = ky*k + kx."""
     Ho, Wo = convT_out(Hi, k), convT_out(Wi, k)
     Hg, Wg = (Ho - py + 1) // 2, (Wo - px + 1) // 2
     taps = convT_phase_taps(k, py, px)
-    g = _geom(n * Hg * Wg, Hg, Wg, Hi, Wi, 1, 1, Ho, Wo, 2, 2, py, px, [(t[2], t[3]) for t in taps], C, C, C, C * C)
-    return g, [t[0] * k + t[1] for t in taps]
+    tap_idx = [t[0] * k + t[1] for t in taps]
+    g = _geom(n * Hg * Wg, Hg, Wg, Hi, Wi, 1, 1, Ho, Wo, 2, 2, py, px, [(t[2], t[3]) for t in taps], C, C, C, C * C,
+              w_taps=tap_idx)
+    return g, tap_idx
 
 
+@functools.lru_cache(maxsize=None)
 def geom_convT_dgrad(n, Hi, Wi, k, C=64):
     """Data gradient of the transposed conv = stride-2 conv over d_out [n,Ho,Wo,C] -> [n,Hi,Wi,C].
-    Returns (geometry, order): tap t of the geometry is kernel tap order[t] = ky*k + kx."""
+    Returns (geometry, order): tap t of the geometry is kernel tap order[t] = ky*k + kx; the weight offsets
+    address the full kernel [k*k][ci][co] in its natural order."""
     Ho, Wo = convT_out(Hi, k), convT_out(Wi, k)
     # taps kx and kx+2 of one kernel row read the same d_out pixels one output column apart: running them
     # back to back turns half of the operand re-reads into L2 hits
     kxs = [kx for par in (0, 1) for kx in range(par, k, 2)]
     order = [ky * k + kx for ky in range(k) for kx in kxs]
     taps = [(t // k - 1, t % k - 1) for t in order]
-    return _geom(n * Hi * Wi, Hi, Wi, Ho, Wo, 2, 2, Hi, Wi, 1, 1, 0, 0, taps, C, C, C, C * C), order
+    return _geom(n * Hi * Wi, Hi, Wi, Ho, Wo, 2, 2, Hi, Wi, 1, 1, 0, 0, taps, C, C, C, C * C, w_taps=order), order
 
 
+@functools.lru_cache(maxsize=None)
 def geom_linear(rows, K, N, a_pitch=None, o_pitch=None):
     """y = x @ W^T with W [N,K] (torch layout); K, N multiples of 64, K <= 2048."""
     assert K % 64 == 0 and N % 64 == 0 and K // 64 <= 32

@@ -30,10 +30,10 @@ struct ConvGeom {
     int ntaps;
     int a_pitch, o_pitch;     // floats per input / output pixel row
     int w_pitch;              // floats between consecutive output columns of W_t ([col][k] layout)
-    long w_tap_stride;        // floats between taps
     long w_nblk_stride;       // floats between 64-column output blocks (blockIdx.y)
     int dy[32], dx[32];       // dword arrays: indexed by the (uniform) tap counter they stay in SGPRs
     int a_col[32];
+    int w_off[32];            // float offset of tap t's 64x64 weight block
 };
 
 struct RowInfo {
@@ -180,10 +180,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
     rows_of_tile(ltile, opix[0]);
 #pragma unroll
     for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], 0, q, &ok[e]);
-    rw0 = *reinterpret_cast<const float4*>(Wn);
-    rw1 = *reinterpret_cast<const float4*>(Wn + w16);
-    rw2 = *reinterpret_cast<const float4*>(Wn + 2 * w16);
-    rw3 = *reinterpret_cast<const float4*>(Wn + 3 * w16);
+    {
+        const float* Wn0 = Wn + g.w_off[0];
+        rw0 = *reinterpret_cast<const float4*>(Wn0);
+        rw1 = *reinterpret_cast<const float4*>(Wn0 + w16);
+        rw2 = *reinterpret_cast<const float4*>(Wn0 + 2 * w16);
+        rw3 = *reinterpret_cast<const float4*>(Wn0 + 3 * w16);
+    }
 
     floatx16 acc0 = {}, acc1 = {};
     int t = 0;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
 #pragma unroll
         for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tn, q, &ok[e]);
         {
-            const float* Wn1 = Wn + tn * g.w_tap_stride;
+            const float* Wn1 = Wn + g.w_off[tn];
             rw0 = *reinterpret_cast<const float4*>(Wn1);
             rw1 = *reinterpret_cast<const float4*>(Wn1 + w16);
             rw2 = *reinterpret_cast<const float4*>(Wn1 + 2 * w16);
@@ -431,8 +434,11 @@ static int check_geom(const ConvGeom& g) {
     CMVAE_REQUIRE((long)(g.rows_total / (g.Hg * g.Wg)) * g.Hi * g.Wi * g.a_pitch < (1L << 31),
                   "conv geometry: input larger than 2^31 elements");
     for (int t = 0; t < g.ntaps; ++t)
+    {
         CMVAE_REQUIRE(g.a_col[t] >= 0 && g.a_col[t] + 64 <= g.a_pitch && g.a_col[t] % 4 == 0,
                       "conv geometry: tap %d column window outside the input row", t);
+        CMVAE_REQUIRE(g.w_off[t] >= 0 && g.w_off[t] % 4 == 0, "conv geometry: tap %d weight offset", t);
+    }
     return 0;
 }
 
@@ -444,9 +450,9 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
     ConvGeom g{};
     g.rows_total = c->rows_total; g.Hg = c->Hg; g.Wg = c->Wg; g.Hi = c->Hi; g.Wi = c->Wi; g.sy = c->sy; g.sx = c->sx;
     g.Ho = c->Ho; g.Wo = c->Wo; g.oys = c->oys; g.oxs = c->oxs; g.oy0 = c->oy0; g.ox0 = c->ox0; g.ntaps = c->ntaps;
-    g.a_pitch = c->a_pitch; g.o_pitch = c->o_pitch; g.w_pitch = c->w_pitch; g.w_tap_stride = c->w_tap_stride;
+    g.a_pitch = c->a_pitch; g.o_pitch = c->o_pitch; g.w_pitch = c->w_pitch;
     g.w_nblk_stride = c->w_nblk_stride;
-    for (int t = 0; t < 32; ++t) { g.dy[t] = c->dy[t]; g.dx[t] = c->dx[t]; g.a_col[t] = c->a_col[t]; }
+    for (int t = 0; t < 32; ++t) { g.dy[t] = c->dy[t]; g.dx[t] = c->dx[t]; g.a_col[t] = c->a_col[t]; g.w_off[t] = c->w_off[t]; }
     return g;
 }
 
@@ -563,8 +569,8 @@ static ConvGeom linear_geom(int rows, int K, int N, int a_pitch, int o_pitch) {
     g.Hg = g.Wg = g.Hi = g.Wi = g.sy = g.sx = g.Ho = g.Wo = g.oys = g.oxs = 1;
     g.ntaps = K / 64;
     g.a_pitch = a_pitch; g.o_pitch = o_pitch; g.w_pitch = K;
-    g.w_tap_stride = 64; g.w_nblk_stride = 64L * K;
-    for (int t = 0; t < g.ntaps; ++t) g.a_col[t] = 64 * t;
+    g.w_nblk_stride = 64L * K;
+    for (int t = 0; t < g.ntaps; ++t) { g.a_col[t] = 64 * t; g.w_off[t] = 64 * t; }
     return g;
 }
 

@@ -83,7 +83,7 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
     """x [n*Hi*Hi,64] (pre-fold) -> y [n*Ho*Ho,64]; returns (y, column sums {sum,sumsq} or None)."""
     Ho = conv.convT_out(Hi, k)
     y = torch.empty(n * Ho * Ho, 64, device=x.device)
-    wprep = weight.detach().permute(2, 3, 1, 0).reshape(k * k, 64, 64)       # [tap][co][ci]
+    wprep = weight.detach().permute(2, 3, 1, 0).contiguous()                 # [ky][kx][co][ci]: all k*k taps
     phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px) for py in (0, 1) for px in (0, 1)]
     part = None
     if want_stats:
@@ -92,9 +92,8 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
     off = 0
     sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
     for i, (g, tap_idx) in enumerate(phases):
-        wp = wprep[tap_idx].contiguous()
         st = part[off:off + grids[i]] if want_stats else False
-        conv.conv_gemm(g, x, wp, y, bias=bias.detach(), a_scale=sc, a_shift=sh, stats=st)
+        conv.conv_gemm(g, x, wprep, y, bias=bias.detach(), a_scale=sc, a_shift=sh, stats=st)
         if want_stats:
             off += grids[i]
     return y, (colsum(part) if want_stats else None)
@@ -172,7 +171,7 @@ class _DecoderBCE(torch.autograd.Function):
                     first = False
             grads_w[li], grads_b[li] = dW, db
             gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k)
-            wtd = ws[li].detach().permute(2, 3, 0, 1).reshape(k * k, 64, 64)[order].contiguous()   # [tap][ci][co]
+            wtd = ws[li].detach().permute(2, 3, 0, 1).contiguous()   # [ky][kx][ci][co]
             d_in = torch.empty(n * Hi * Hi, 64, device=dev)
             conv.conv_gemm(gd, dy, wtd, d_in)
             d = d_in

@@ -138,13 +138,14 @@ int cmvae_expm_trace(const float* A, float* h, float* grad, void* stream);
  * r enumerates (image, y, x) over the per-image grid [Hg,Wg]; src(r,t) = (image, y*sy+dy[t],
  * x*sx+dx[t]) in the [Hi,Wi] input image (zero outside); outpix(r) = (image, y*oys+oy0,
  * x*oxs+ox0) in the [Ho,Wo] output image.  W_t is stored [out col][k] (k contiguous):
- * W + nb*w_nblk_stride + t*w_tap_stride + col*w_pitch + k.  T = relu(a*a_scale[c]+a_shift[c])
+ * W + nb*w_nblk_stride + w_off[t] + col*w_pitch + k  (per-tap offsets: a sub-pixel phase picks its taps out of
+ * the full [k*k][64][64] kernel without a gather).  T = relu(a*a_scale[c]+a_shift[c])
  * when a_scale != NULL (the previous BatchNorm+ReLU folded into the operand load).          */
 typedef struct cmvae_conv_geom {
     int32_t rows_total, Hg, Wg, Hi, Wi, sy, sx, Ho, Wo, oys, oxs, oy0, ox0, ntaps;
     int32_t a_pitch, o_pitch, w_pitch;
-    int64_t w_tap_stride, w_nblk_stride;
-    int32_t dy[32], dx[32], a_col[32];
+    int64_t w_nblk_stride;
+    int32_t dy[32], dx[32], a_col[32], w_off[32];
 } cmvae_conv_geom;
 
 /* act: 0 none, 1 ReLU, 2 ELU.  stats_part (optional, n_col_blocks == 1): per-block partial

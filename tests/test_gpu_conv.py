@@ -79,7 +79,7 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k):
     for py in (0, 1):
         for px in (0, 1):
             geom, tap_idx = conv.geom_convT_phase(n, Hi, Hi, k, py, px)
-            wp = wprep[tap_idx].contiguous()
+            wp = wprep
             part = conv.conv_gemm(geom, xd, wp, out, bias=bd, a_scale=scd, a_shift=shd, stats=True)
             ssum += part.sum(0).cpu()
             conv.conv_wgrad(geom, xd, gyd, dW, tap_idx, s_ci=64 * k * k, s_co=k * k, db=db, accumulate_db=not first,
@@ -91,7 +91,7 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k):
     assert rel_err(db, b.grad) < TOL
     # data gradient wrt a (the post-activation input)
     gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k)
-    wtd = w.detach().permute(2, 3, 0, 1).reshape(k * k, 64, 64)[order].contiguous().to(device)      # [tap][ci][co]
+    wtd = w.detach().permute(2, 3, 0, 1).contiguous().to(device)      # [ky][kx][ci][co]
     da = torch.empty(n * Hi * Hi, 64, device=device)
     conv.conv_gemm(gd, gyd, wtd, da)
     assert rel_err(from_nhwc(da.cpu(), n, Hi, Hi), a.grad) < TOL

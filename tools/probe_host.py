@@ -15,7 +15,7 @@ N = bench.SAMPLE * bench.MC
 
 def step():
     model.train(); flat.zero()
-    idx = torch.from_numpy(cdist.draw_em_init(N, bench.WAY, bench.B_PER_GPU, 0, 1)).to(dev)
+    idx = torch.from_numpy(cdist.draw_em_init(N, bench.WAY, bench.B_PER_GPU, 0, 1)).pin_memory().to(dev, non_blocking=True)
     _, rec, kl, h, _ = model(X, 0.1, 0.1, 1e-4, init_idx=idx)
     (rec + kl + h).backward()
     flat.allreduce(); opt.step()
@@ -33,4 +33,4 @@ if len(sys.argv) > 1:
     for _ in range(5):
         step()
     torch.cuda.synchronize(); pr.disable()
-    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(35); print(s.getvalue()[:6000])
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(45); print(s.getvalue()[:9000])
