@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcmvae_hip.so')
+LIB_PATH = os.environ.get('CMVAE_HIP_LIB') or os.path.join(_HERE, 'libcmvae_hip.so')      # override: profiling builds
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

@@ -12,6 +12,9 @@
 // math (exact fp32 fma chains); A and W_t tiles are staged through LDS with register prefetch.
 // The weight-gradient kernel contracts over r instead.
 #include "common.h"
+#ifndef CMVAE_ABLATE
+#define CMVAE_ABLATE 0
+#endif
 
 namespace cmvae {
 
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
             sc = *reinterpret_cast<const float4*>(a_scale + g.a_col[t] + 4 * q);
             sh = *reinterpret_cast<const float4*>(a_shift + g.a_col[t] + 4 * q);
         }
+#if !(CMVAE_ABLATE & 2)
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
         *reinterpret_cast<float4*>(&Ws[(rb + 32) * LDA + 4 * q]) = rw2;
         *reinterpret_cast<float4*>(&Ws[(rb + 48) * LDA + 4 * q]) = rw3;
         __syncthreads();
+#endif
         // operands of the next step (past the block's last step the rows are all invalid: element 0 is read)
         int tn = t + 1;
         if (tn == g.ntaps) {
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
             ltile += gridDim.x;
             rows_of_tile(ltile, opix[par ^ 1]);
         }
+#if !(CMVAE_ABLATE & 1)
 #pragma unroll
         for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tn, q, &ok[e]);
         {
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
             rw2 = *reinterpret_cast<const float4*>(Wn1 + 2 * w16);
             rw3 = *reinterpret_cast<const float4*>(Wn1 + 3 * w16);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs that hide it
         const float* ap = &As[(32 * w + i) * LDA + 4 * h];
         const float* bp0 = &Ws[i * LDA + 4 * h];
@@ -287,7 +294,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
 
 // ---------------------------------------------------------------------------- weight gradient
 // part[blk][t][ci][co] = sum_r T(A[src(r,t)])[ci] * G[outpix(r)][g_col + co]
-template <int NT>
+// Same software pipeline as the forward kernel: while the 64 MFMAs of a tap run, the next tap's operand rows (or
+// the next tile's gradient rows and first tap) are in flight; LDS fragments are read four row-pairs ahead.
+template <int NT, bool HAS_T>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0, const float* __restrict__ A,
                                                             const float* __restrict__ a_scale,
                                                             const float* __restrict__ a_shift,
@@ -299,7 +308,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
     const int i = lane & 31, h = lane >> 5;
     const int q = tid & 15, rb = tid >> 4;
     const int ci_h = w >> 1, co_h = w & 1;
-    const bool has_t = a_scale != nullptr;
     const int ntiles = (g.rows_total + BM - 1) / BM;
     // grid.y walks 64-column blocks of G, grid.z groups of NT taps; every (y, z) owns a slab of partials
     tap0 += NT * blockIdx.z;
@@ -310,50 +318,77 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
         if (db_part) db_part += slot * 64;
         if (blockIdx.z != 0) db_part = nullptr;
     }
+    const RowDecoder dec(g);
     floatx16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = floatx16{};
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        RowInfo ri[8];
-        float4 rg[8], ra[8];
-        bool ok[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
+    RowInfo ri[8];
+    float4 rg[8], ra[8];
+    bool ok[8];
+    // rows of a tile: operand row info + the tile's gradient rows (zero past the end), first tap in flight
+    auto open_tile = [&](int tile) {
+        dec.decode<8>(tile * BM + rb, 16, [&](int e, int n, int y, int x) {
             const int r = tile * BM + rb + 16 * e;
-            ri[e] = row_info(g, r);
-            const int op = out_pixel(g, r);
-            rg[e] = *reinterpret_cast<const float4*>(G + (long)(op >= 0 ? op : 0) * g_pitch + g_col + 4 * q);
-            if (op < 0) rg[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            dbs.x += rg[e].x; dbs.y += rg[e].y; dbs.z += rg[e].z; dbs.w += rg[e].w;
-            ra[e] = load_a(g, A, ri[e], tap0, q, &ok[e]);
-        }
-        __syncthreads();
+            ri[e] = make_row(g, r, n, y, x);
+            const bool rv = r < g.rows_total;
+            const int op = rv ? (n * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0 : 0;
+            float4 v = *reinterpret_cast<const float4*>(G + (long)op * g_pitch + g_col + 4 * q);
+            v.x = rv ? v.x : 0.f; v.y = rv ? v.y : 0.f; v.z = rv ? v.z : 0.f; v.w = rv ? v.w : 0.f;
+            rg[e] = v;
+        });
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<float4*>(&Gs[(rb + 16 * e) * 64 + 4 * q]) = rg[e];
+        for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tap0, q, &ok[e]);
+    };
+    open_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has_t) {
+            if (HAS_T) {
                 sc = *reinterpret_cast<const float4*>(a_scale + g.a_col[tap0 + t] + 4 * q);
                 sh = *reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t] + 4 * q);
             }
-            if (t > 0) __syncthreads();
+            __syncthreads();
+            if (t == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    *reinterpret_cast<float4*>(&Gs[(rb + 16 * e) * 64 + 4 * q]) = rg[e];
+                    dbs.x += rg[e].x; dbs.y += rg[e].y; dbs.z += rg[e].z; dbs.w += rg[e].w;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<float4*>(&As[(rb + 16 * e) * 64 + 4 * q]) =
-                    (has_t ? transform_a<true>(ra[e], ok[e], sc, sh) : transform_a<false>(ra[e], ok[e], sc, sh));
+                *reinterpret_cast<float4*>(&As[(rb + 16 * e) * 64 + 4 * q]) = transform_a<HAS_T>(ra[e], ok[e], sc, sh);
             __syncthreads();
             if (t + 1 < NT) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tap0 + t + 1, q, &ok[e]);
+            } else {
+                open_tile(tile + gridDim.x);        // past the last tile every row is invalid: element 0 is read
             }
+            __builtin_amdgcn_sched_barrier(0);
             const float* ap = &As[h * 64 + 32 * ci_h + i];
             const float* gp = &Gs[h * 64 + 32 * co_h + i];
-#pragma unroll 16
-            for (int rr = 0; rr < BM / 2; ++rr)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[rr * 128], gp[rr * 128], acc[t], 0, 0, 0);
+            float a0 = ap[0], a1 = ap[128], a2 = ap[256], a3 = ap[384];
+            float g0 = gp[0], g1 = gp[128], g2 = gp[256], g3 = gp[384];
+#pragma unroll
+            for (int b4 = 0; b4 < BM / 8; ++b4) {
+                float n0 = a0, n1 = a1, n2 = a2, n3 = a3, m0 = g0, m1 = g1, m2 = g2, m3 = g3;
+                if (b4 + 1 < BM / 8) {
+                    const float* an = ap + (b4 + 1) * 512;
+                    const float* gn = gp + (b4 + 1) * 512;
+                    n0 = an[0]; n1 = an[128]; n2 = an[256]; n3 = an[384];
+                    m0 = gn[0]; m1 = gn[128]; m2 = gn[256]; m3 = gn[384];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, g0, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, g1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, g2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, g3, acc[t], 0, 0, 0);
+                a0 = n0; a1 = n1; a2 = n2; a3 = n3; g0 = m0; g1 = m1; g2 = m2; g3 = m3;
+            }
         }
     }
     float* pb = part + (long)blockIdx.x * NT * 4096;
@@ -529,10 +564,10 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
         float* dbp = (db && t0 == 0) ? db_part : nullptr;
         const dim3 grid(nblk, ny, nz);
         switch (nt) {
-            case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            case 2: hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            default: hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 1: if (a_scale) hipLaunchKernelGGL((conv_wgrad_kernel<1, true>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); else hipLaunchKernelGGL((conv_wgrad_kernel<1, false>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 2: if (a_scale) hipLaunchKernelGGL((conv_wgrad_kernel<2, true>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); else hipLaunchKernelGGL((conv_wgrad_kernel<2, false>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 3: if (a_scale) hipLaunchKernelGGL((conv_wgrad_kernel<3, true>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); else hipLaunchKernelGGL((conv_wgrad_kernel<3, false>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            default: if (a_scale) hipLaunchKernelGGL((conv_wgrad_kernel<4, true>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); else hipLaunchKernelGGL((conv_wgrad_kernel<4, false>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
         }
         if (int e = check_launch("conv_wgrad_kernel")) return e;
         for (int t = 0; t < nt * nz; ++t) o.tap_off[t] = tap_off_host[t0 + t];
