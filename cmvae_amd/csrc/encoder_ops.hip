@@ -9,11 +9,15 @@ namespace cmvae {
 constexpr int EC = 64;
 
 // ------------------------------------------------------------------ conv 1->64, 3x3, pad 1
-// x [n,H,W]; w [64][9]; y [n*H*W, 64]; part[blk][128] = {sum y, sum y^2} (optional)
+// x [n,H,W]; w [64][9]; y [n*H*W, 64]; part[blk][128] = {sum y, sum y^2} (optional).
+// One image per workgroup pass: the image sits zero-padded in LDS (taps never branch, 16 lanes broadcast-read one
+// pixel), a thread owns 4 channels and writes one float4 of a 256-B output row -> HBM-bound on the 64-channel output.
+constexpr int EC1_MAX = 34 * 34;       // padded image, H, W <= 32
 __global__ __launch_bounds__(256) void enc_conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ b, int H, int W, long rows,
+                                                            const float* __restrict__ b, int H, int W, int nimg,
                                                             float* __restrict__ y, float* __restrict__ part) {
     __shared__ float red[16 * 128];
+    __shared__ float xs[EC1_MAX];
     const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
     float wr[4][9], br[4];
 #pragma unroll
@@ -23,29 +27,35 @@ __global__ __launch_bounds__(256) void enc_conv1_fwd_kernel(const float* __restr
         for (int t = 0; t < 9; ++t) wr[c][t] = w[(4 * q + c) * 9 + t];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const int hw = H * W;
-    for (long r = (long)blockIdx.x * 16 + rb; r < rows; r += (long)gridDim.x * 16) {
-        const long n = r / hw;
-        const int rem = (int)(r - n * hw);
-        const int py = rem / W, px = rem - py * W;
-        const float* xi = x + n * hw;
-        float acc[4] = {br[0], br[1], br[2], br[3]};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int sy = py + ky - 1;
-            if (sy < 0 || sy >= H) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int sx = px + kx - 1;
-                if (sx < 0 || sx >= W) continue;
-                const float xv = xi[sy * W + sx];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, wr[c][ky * 3 + kx], acc[c]);
-            }
+    const int hw = H * W, PW = W + 2;
+    for (int e = threadIdx.x; e < (H + 2) * PW; e += 256) xs[e] = 0.f;
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+        __syncthreads();
+        const float* xi = x + (long)img * hw;
+        for (int e = threadIdx.x; e < hw; e += 256) {
+            const int py = e / W;
+            xs[(py + 1) * PW + (e - py * W) + 1] = xi[e];
         }
-        reinterpret_cast<float4*>(y + r * EC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        float* yi = y + (long)img * hw * EC;
+        int py = rb / W, px = rb - py * W;
+        for (int pix = rb; pix < hw; pix += 16) {
+            const float* xp = &xs[py * PW + px];
+            float acc[4] = {br[0], br[1], br[2], br[3]};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float xv = xp[ky * PW + kx];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, wr[c][ky * 3 + kx], acc[c]);
+                }
+            reinterpret_cast<float4*>(yi + pix * EC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
+            px += 16;
+            while (px >= W) { px -= W; ++py; }
+        }
     }
     if (part) {
 #pragma unroll
@@ -221,9 +231,10 @@ using namespace cmvae;
 
 extern "C" int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* b, int n, int H, int W, float* y,
                                    float* stats_part, void* stream) {
-    CMVAE_REQUIRE(x && w && b && y && n >= 1 && H >= 1 && W >= 1, "cmvae_enc_conv1_fwd: bad arguments");
+    CMVAE_REQUIRE(x && w && b && y && n >= 1 && H >= 1 && W >= 1 && H <= 32 && W <= 32,
+                  "cmvae_enc_conv1_fwd: bad arguments (images up to 32x32)");
     const long rows = (long)n * H * W;
-    hipLaunchKernelGGL(enc_conv1_fwd_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, w, b, H, W, rows,
+    hipLaunchKernelGGL(enc_conv1_fwd_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, w, b, H, W, n,
                        y, stats_part);
     return check_launch("enc_conv1_fwd_kernel");
 }
