@@ -119,6 +119,23 @@ class _GMVAEBase(nn.Module):
                           log_q_z=log_q_z, log_p_eps=log_p_eps, q_z=q_z, q_eps=q_eps, A=A)
         return kl_loss, h_augment, h
 
+    def _tr_predict_from_posterior(self, q_mean, q_logvar, eps, init_idx):
+        """Cluster labels of the items of a training meta-batch under the unsupervised prior
+        (GMVAE.tr_prediction, omniglot/model.py:587-629): EM, then the few-shot posterior kernel with unit
+        variances and the EM's log-weights."""
+        B, S, D = q_mean.shape
+        M = self.train_mc_sample_size
+        if eps is None:
+            eps = self._draw_eps(q_mean, M)
+        q_z, _ = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
+        q_z = q_z.view(B, S * M, D)
+        pi_k, mu_k, trace_k, logw = self.get_unsupervised_prior(q_z, init_idx)
+        y_pred, _ = ops.posterior_argmax(q_z, mu_k, torch.zeros_like(mu_k), logw, S, M, want_post=False)
+        return y_pred
+
+    def te_prediction(self, X_tr, y_tr, X_te):
+        return self.prediction(X_tr, y_tr, X_te)
+
     def _predict_from_posterior(self, q_mean, q_logvar, y_tr, tr, te, eps, extras):
         B = q_mean.shape[0]
         D, Mt = self.latent_size, self.test_mc_sample_size
@@ -201,6 +218,45 @@ class OmniglotGMVAE(_GMVAEBase):
             return self._predict_from_posterior(q_mean, q_logvar, y_tr, tr, te, eps, extras)
 
 
+    def tr_prediction(self, X, eps=None, init_idx=None):
+        with torch.no_grad():
+            q_mean, q_logvar = self._encode(X)
+            return self._tr_predict_from_posterior(q_mean, q_logvar, eps, init_idx)
+
+    def _decode(self, z):
+        """z [n,64] -> images [n,1,28,28]: causal layer, proj, decoder (no likelihood target)."""
+        D = self.latent_size
+        h = torch.cat([z, self.causal(z)], -1).view(-1, 2 * D)
+        h = linear(h, self.proj[0].weight, self.proj[0].bias, 'elu')
+        h = linear(h, self.proj[2].weight, self.proj[2].bias, 'elu')
+        perm = nhwc_perm(h.device)
+        H_rec = linear(h, self.proj[4].weight[perm], self.proj[4].bias[perm], 'elu')
+        p, _ = decoder_bce(self.decoder, H_rec, torch.zeros(H_rec.shape[0], 784, device=z.device), 1)
+        return p.view(-1, *self.input_shape)
+
+    def generate(self, X_tr, y_tr, X_te, seed=None, eps=None, causes=(0, 58)):
+        """Figure helper (omniglot/model.py:634-723) for episode 0: (True_X, Recon_X, Component_X, Recon_X_2) —
+        reconstructions of the first MC sample of each query item, of the component means, and of the latents
+        with the coordinates `causes` zeroed and re-encoded as z - causal(z)."""
+        tr, te = X_tr.shape[1], X_te.shape[1]
+        B, D, Mt = X_tr.shape[0], self.latent_size, self.test_mc_sample_size
+        with torch.no_grad():
+            q_mean, q_logvar = self._encode(torch.cat([X_tr, X_te], dim=1))
+            if eps is None:
+                eps = self._draw_eps(q_mean, self.train_mc_sample_size)
+            q_z, _ = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
+            uz = q_z[:, tr:tr + te].reshape(B, te * Mt, D).contiguous()
+            sz = q_z[:, :tr].reshape(B, tr * Mt, D).contiguous()
+            y = y_tr.reshape(B * tr)[:, None].repeat(1, Mt).view(B, tr * Mt)
+            pi_k, mu_k, lv_k, trace, logw = self.get_semisupervised_prior(uz, sz, y)
+            z_to = uz.view(B, te, Mt, D)[0, :, 0, :].clone()
+            Recon_X = self._decode(z_to)
+            Component_X = self._decode(mu_k[0].contiguous())
+            z_to[:, list(causes)] = 0
+            Recon_X_2 = self._decode(z_to - self.causal(z_to))
+        return X_te[0], Recon_X, Component_X, Recon_X_2
+
+
 class FeatureGMVAE(_GMVAEBase):
     """MLP-VAE variant over pre-extracted SimCLR features (mimgnet/model.py; celeba/model.py with
     linear=False)."""
@@ -241,6 +297,11 @@ class FeatureGMVAE(_GMVAEBase):
         if extras is not None:
             extras.update(q_z_mean=q_mean, q_z_logvar=q_logvar)
         return H_rec, rec_loss, kl_loss, h_augment, h
+
+    def tr_prediction(self, H, eps=None, init_idx=None):
+        with torch.no_grad():
+            q_mean, q_logvar = self._posterior_head(H).split(self.latent_size, dim=-1)
+            return self._tr_predict_from_posterior(q_mean, q_logvar, eps, init_idx)
 
     def prediction(self, H_tr, y_tr, H_te, eps=None, extras=None):
         tr, te = H_tr.shape[1], H_te.shape[1]

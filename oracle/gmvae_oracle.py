@@ -404,6 +404,54 @@ class OracleGMVAE:
         return y_pred
 
 
+    # -- inspection helpers (omniglot/model.py:587-629, 634-723)
+    def tr_prediction(self, X, eps=None, init_idx=None):
+        """Cluster label of every training item under the unsupervised prior (omniglot/model.py:587-629)."""
+        B, S = X.shape[:2]
+        M, D, K = self.train_mc, self.D, self.K
+        with torch.no_grad():
+            q_mean, q_logvar = self.encode(X)
+            q_z = self.reparametrize(q_mean, q_logvar, M, eps).view(B, -1, D)
+            pi_k, mu_k, tr_k = self.unsup_prior(q_z, init_idx)
+            ll = self._glp(
+                q_z.view(B, S, M, D)[:, :, :, None, :].repeat(1, 1, 1, K, 1),
+                mu_k[:, None, None, :, :].repeat(1, S, M, 1, 1),
+            ) + torch.log(pi_k[:, None, None, :].repeat(1, S, M, 1)) + self._glp(
+                self._causal(mu_k), torch.log(tr_k)[:, :, None].repeat(1, 1, D)
+            ).unsqueeze(1).unsqueeze(2)
+            post = torch.exp(ll - torch.logsumexp(ll, dim=-1, keepdim=True))
+            return post.mean(dim=-2).argmax(dim=-1)
+
+    def generate(self, X_tr, y_tr, X_te, eps=None, causes=(0, 58)):
+        """(True_X, Recon_X, Component_X, Recon_X_2) of episode 0 (omniglot/model.py:634-723): reconstructions of
+        the first MC sample of every query item, of the component means, and of the intervened latents (the
+        coordinates `causes` set to zero, then z - causal(z) re-encoded).  As in the reference the intervention
+        writes through the view, so Recon_X_2 starts from the zeroed z."""
+        assert self.variant == 'omniglot'
+        B, tr = X_tr.shape[:2]
+        te = X_te.shape[1]
+        D, K, Mt = self.D, self.K, self.test_mc
+        with torch.no_grad():
+            q_mean, q_logvar = self.encode(torch.cat([X_tr, X_te], dim=1))
+            q_z = self.reparametrize(q_mean, q_logvar, self.train_mc, eps)
+            uz = q_z[:, tr:(tr + te)].reshape(B, te * Mt, D)
+            sz = q_z[:, :tr].reshape(B, tr * Mt, D)
+            y = F.one_hot(y_tr.reshape(B * tr)[:, None].repeat(1, Mt).view(B, tr * Mt), K).to(q_z.dtype)
+            pi_k, mu_k, lv_k, trace = self.semi_prior(uz, sz, y)
+
+            def decode(z):
+                H = proj(torch.cat([z, self._causal(z)], -1), self.P, F.elu)
+                return omniglot_decoder(H, self.P, self.training, self.hidden, self.running)
+
+            z_to = uz.view(B, te, Mt, D)[0, :, 0, :].clone()
+            Recon_X = decode(z_to)
+            Component_X = decode(mu_k[0])
+            z_to[:, list(causes)] = 0
+            z_ = z_to - self._causal(z_to)
+            Recon_X_2 = decode(z_)
+        return X_te[0], Recon_X, Component_X, Recon_X_2
+
+
 # ----------------------------------------------------------------------------- CPU baseline helper
 def make_trainable(P):
     """Clone a state dict into leaf tensors that require grad (floating-point, >0-dim, non-buffer)."""

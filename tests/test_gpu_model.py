@@ -182,3 +182,37 @@ def test_hip_path_matches_golden_vectors(device, name):
     K = c['K']
     y = model2.prediction(X[:, :K].to(device), y_tr.to(device), X[:, K:].to(device), eps=eps.to(device))
     assert np.array_equal(y.cpu().numpy(), gold['y_pred'])
+
+
+@pytest.mark.parametrize('variant,linear', [('omniglot', False), ('feat', True)])
+def test_tr_prediction_bit_exact(device, variant, linear):
+    """GMVAE.tr_prediction (omniglot/model.py:587-629): cluster labels of the training items."""
+    B, S, K, M = 2, 24, 4, 6
+    model, oracle = build_pair(variant, K=K, M=M, iters=3, linear=linear)
+    X = omniglot_batch(B, S, seed=5) if variant == 'omniglot' else feature_batch(B, S, 256, seed=5)
+    eps = torch.randn(B, S, M, 64, generator=torch.Generator().manual_seed(6))
+    rng = np.random.RandomState(2)
+    idx = np.stack([rng.choice(S * M, K, replace=False) for _ in range(B)], 0)
+    oracle.training = False
+    y_o = oracle.tr_prediction(X, eps=eps, init_idx=idx)
+    model.to(device).eval()
+    y_g = model.tr_prediction(X.to(device), eps=eps.to(device), init_idx=torch.from_numpy(idx).to(device))
+    assert y_g.dtype == torch.int64 and tuple(y_g.shape) == (B, S)
+    assert torch.equal(y_g.cpu(), y_o)
+
+
+def test_generate_matches_oracle(device):
+    """GMVAE.generate (omniglot/model.py:634-723): reconstructions, component images, intervened reconstructions."""
+    B, K, shot, query, M = 2, 5, 2, 3, 4
+    model, oracle = build_pair('omniglot', K=K, M=M, iters=3, linear=False)
+    tr, te = K * shot, K * query
+    X = omniglot_batch(B, tr + te, seed=9)
+    y_tr = torch.arange(K).repeat_interleave(shot)[None].repeat(B, 1)
+    eps = torch.randn(B, tr + te, M, 64, generator=torch.Generator().manual_seed(10))
+    oracle.training = False
+    outs_o = oracle.generate(X[:, :tr], y_tr, X[:, tr:], eps=eps)
+    model.to(device).eval()
+    outs_g = model.generate(X[:, :tr].to(device), y_tr.to(device), X[:, tr:].to(device), eps=eps.to(device))
+    assert tuple(outs_g[1].shape) == (te, 1, 28, 28) and tuple(outs_g[2].shape) == (K, 1, 28, 28)
+    for a, b in zip(outs_g, outs_o):
+        assert rel_err(a, b) < RTOL
