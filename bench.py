@@ -202,11 +202,13 @@ def main():
     h_lambda, h_c, a_lambda = 0.1, 0.1, 1e-4
     N = SAMPLE * MC
 
+    seeds = cdist.SeedUploader((B_PER_GPU, WAY), device)
+
     def step(i):
         model.train()
         flat.zero()
         X = pool[i % n_pool]
-        idx = torch.from_numpy(cdist.draw_em_init(N, WAY, B_PER_GPU * world, rank, world)).to(device)
+        idx = seeds.upload(cdist.draw_em_init(N, WAY, B_PER_GPU * world, rank, world))
         _, rec, kl, h_aug, _ = model(X, h_lambda, h_c, a_lambda, init_idx=idx)
         (rec + kl + h_aug).backward()
         flat.allreduce()

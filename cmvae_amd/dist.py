@@ -59,6 +59,30 @@ def draw_em_init(n_samples, k, b_global, r=None, ws=None):
     return idx[shard_slice(b_global, r, ws)].astype(np.int64)
 
 
+class SeedUploader:
+    """EM seeds host -> device without stalling the host: a ring of pinned buffers and asynchronous copies.
+    (A plain `.to(device)` from pageable memory blocks the host until everything queued before it has run, which
+    drains the launch queue once per step.)"""
+
+    def __init__(self, shape, device, depth=4):
+        self.device = torch.device(device)
+        self.pinned = [torch.empty(shape, dtype=torch.int64).pin_memory() for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def upload(self, idx_numpy):
+        k = self.i
+        self.i = (k + 1) % len(self.pinned)
+        if self.events[k] is not None:
+            self.events[k].synchronize()                 # the copy that last used this buffer has run
+        self.pinned[k].copy_(torch.from_numpy(idx_numpy))
+        out = self.pinned[k].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return out
+
+
 def gather_episode_values(values, local_batch):
     """Per-episode values [n_calls * local_batch] of every rank -> one vector in global episode order
     (call t holds the episodes t*B_g ... (t+1)*B_g - 1, rank r owns the r-th contiguous slice of them).

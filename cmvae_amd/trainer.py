@@ -50,6 +50,7 @@ class Trainer(object):
         self.model = self._new_model()
         self.flat = cdist.FlatGrads(self.model.parameters())
         self.optimizer = FlatAdam(self.flat, lr=args.lr, weight_decay=args.weight_decay)
+        self.seeds = cdist.SeedUploader((self.local_batch, args.way), self.device)
         self.log_interval = max(1, int(getattr(args, 'log_interval', 50)))
         self.best_files = {}
         self.log_path = os.path.join(args.save_dir, 'train_log.jsonl')
@@ -80,7 +81,7 @@ class Trainer(object):
         shape = self.input_shape if isinstance(self.input_shape, list) else [self.input_shape]
         X = X.view(a.batch_size, a.sample_size, *shape)[cdist.shard_slice(a.batch_size, self.rank, self.world)]
         idx = cdist.draw_em_init(a.sample_size * a.train_mc_sample_size, a.way, a.batch_size, self.rank, self.world)
-        idx = torch.from_numpy(idx).to(self.device, non_blocking=True)
+        idx = self.seeds.upload(idx)
         X_rec, rec_loss, kl_loss, h_augment, h = self.model(X, h_lambda, h_c, a_lambda, init_idx=idx)
         (rec_loss + kl_loss + h_augment).backward()
         self.flat.allreduce()
