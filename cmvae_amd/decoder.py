@@ -145,8 +145,9 @@ class _DecoderBCE(torch.autograd.Function):
         part = torch.empty(lib.cmvae_dec_out_grid(n), L, device=dev)
         d = torch.empty(n * 196, 64, device=dev)
         g_loss = g_loss.contiguous().float()
+        # pass 1: dW4, db4 and the BatchNorm-backward sums of layer 3 (the masked gradient itself is not stored)
         check(lib.cmvae_dec_out_bwd(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n, _p(g_loss),
-                                    1.0, _p(d), _p(part), _stream()), 'cmvae_dec_out_bwd')
+                                    1.0, None, _p(part), _stream()), 'cmvae_dec_out_bwd')
         tot = colsum(part)
         dw4 = tot[:1024].reshape(64, 1, 4, 4)
         db4 = tot[1152:1153]
@@ -157,7 +158,14 @@ class _DecoderBCE(torch.autograd.Function):
             k, Hi = _LAYERS[li]
             y, fold, x_in, fold_in = acts[li + 1], folds[li + 1], acts[li], folds[li]
             c1, c2, dgamma, dbeta = bn_bwd_finalize(sums, y.shape[0])
-            dy = bn_relu_bwd_apply(d, y, fold, c1, c2, masked, out=d)             # in place
+            if li == 2:
+                # pass 2 of the last layer's backward writes dy3 directly
+                check(lib.cmvae_dec_out_bwd_apply(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
+                                                  _p(g_loss), 1.0, _p(c1), _p(c2), _p(d), _stream()),
+                      'cmvae_dec_out_bwd_apply')
+                dy = d
+            else:
+                dy = bn_relu_bwd_apply(d, y, fold, c1, c2, masked, out=d)             # in place
             grads_g[li], grads_be[li] = dgamma, dbeta
             dW = torch.empty_like(ws[li])
             db = torch.empty(64, device=dev)

@@ -234,7 +234,7 @@ int cmvae_bn_relu_bwd_apply(const float* d_a, const float* y, const float* scale
  * (omniglot/module.py:62-63, omniglot/model.py:83,463-466).  y3 [nimg,14,14,64]; w4 [64,16];
  * target [nimg/M, 784] (the image each MC sample reconstructs); p_out [nimg,784];
  * loss_part [nimg] (per-image BCE sums, log clamped at -100 as nn.BCELoss does).
- * bwd: dybn [nimg,14,14,64] = masked gradient w.r.t. bn3 output; part
+ * bwd: dybn [nimg,14,14,64] = masked gradient w.r.t. bn3 output (NULL: not stored, sums only); part
  * [cmvae_dec_out_grid(nimg)][cmvae_dec_out_bwd_partial_len()] = {dW4[64][16], sum dybn[64],
  * sum dybn*xhat[64], db4}.  Upstream gradient of the BCE sum = gmul * g_dev[0] (g_dev: device
  * scalar or NULL for 1).                                                                       */
@@ -245,6 +245,13 @@ int cmvae_dec_out_fwd(const float* y3, const float* scale, const float* shift, c
 int cmvae_dec_out_bwd(const float* y3, const float* scale, const float* shift, const float* mean,
                       const float* invstd, const float* w4, const float* p, const float* target, int M, int nimg,
                       const float* g_dev, float gmul, float* dybn, float* part, void* stream);
+/* Second pass of the same backward: with c1, c2 from cmvae_bn_bwd_finalize (computed from the sums of the first
+ * pass, called with dybn == NULL) it recomputes the masked gradient and writes the gradient at layer 3's
+ * pre-BatchNorm output, dy3 = scale*(dybn3 - c1 - xhat*c2), so dybn3 never travels through HBM.               */
+int cmvae_dec_out_bwd_apply(const float* y3, const float* scale, const float* shift, const float* mean,
+                            const float* invstd, const float* w4, const float* p, const float* target,
+                            int M, int nimg, const float* g_dev, float gmul, const float* c1, const float* c2,
+                            float* dy, void* stream);
 
 /* ==== OmniglotEncoder pieces that are not 64->64 GEMMs (omniglot/module.py:12-33)
  * Conv2d(1,64,3,1,1): x [n,H,W] -> y [n*H*W,64]; w [64,9]; stats_part (optional)
