@@ -1,0 +1,93 @@
+"""Episode-sharded data parallelism on the real kernels: two ranks share the one GPU of the test box and talk over
+gloo (RCCL refuses two ranks on one device; the collectives' call sites are the same).  A step on the sharded
+meta-batch must equal the single-process step on the whole meta-batch: BatchNorm statistics span all episodes
+(collective C2 inside the HIP encoder / decoder pipelines), gradients are averaged (C1), EM seeds come from the shared
+numpy stream."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+B, S, K, M = 2, 12, 3, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(device):
+    from cmvae_amd.model import OmniglotGMVAE
+    torch.manual_seed(4)
+    return OmniglotGMVAE(component_size=K, train_mc_sample_size=M, test_mc_sample_size=M, unsupervised_em_iters=3,
+                         semisupervised_em_iters=3).to(device).train()
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(5)
+    X = (torch.rand(B, S, 1, 28, 28, generator=g) < 0.15).float()
+    eps = torch.randn(B, S, M, 64, generator=g)
+    return X, eps
+
+
+def _step(model, flat, opt, X, eps, idx, device):
+    flat.zero()
+    _, rec, kl, h_aug, _ = model(X.to(device), 0.1, 0.1, 1e-4, eps=eps.to(device), init_idx=torch.from_numpy(idx).to(device))
+    (rec + kl + h_aug).backward()
+    flat.allreduce()
+    grads = flat.flat.clone()
+    opt.step()
+    return torch.stack([rec.detach(), kl.detach(), h_aug.detach()]).cpu(), grads.cpu()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    from cmvae_amd import dist as cdist
+    from cmvae_amd.linear import FlatAdam
+    cdist.init_from_env('gloo')
+    device = torch.device('cuda:0')
+    model = _build(device)
+    flat = cdist.FlatGrads(model.parameters())
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
+    X, eps = _inputs()
+    sl = cdist.shard_slice(B)
+    np.random.seed(21)
+    idx = cdist.draw_em_init(S * M, K, B)
+    losses, grads = _step(model, flat, opt, X[sl], eps[sl], idx, device)
+    out[rank] = dict(losses=losses, grads=grads, w=model.proj[0].weight.detach().cpu().clone(),
+                     rm=model.decoder.decoder[1].running_mean.detach().cpu().clone())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_on_hip_kernels_equal_one_process(device):
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    from cmvae_amd import dist as cdist
+    from cmvae_amd.linear import FlatAdam
+    model = _build(device)
+    flat = cdist.FlatGrads(model.parameters())
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
+    X, eps = _inputs()
+    np.random.seed(21)
+    idx = np.stack([np.random.choice(S * M, K, replace=False) for _ in range(B)], 0).astype(np.int64)
+    losses, grads = _step(model, flat, opt, X, eps, idx, device)
+    # every loss term is a mean over equal-sized shards (h_augment is replicated)
+    mean_losses = (out[0]['losses'] + out[1]['losses']) / 2
+    assert torch.allclose(mean_losses, losses, rtol=2e-5, atol=1e-6), (mean_losses, losses)
+    scale = float(grads.abs().max())
+    for r in range(world):
+        assert float((out[r]['grads'] - grads).abs().max()) < 2e-4 * scale
+        assert torch.allclose(out[r]['w'], model.proj[0].weight.detach().cpu(), atol=1e-5)
+        assert torch.allclose(out[r]['rm'], model.decoder.decoder[1].running_mean.detach().cpu(), atol=1e-6)
+    assert torch.equal(out[0]['grads'], out[1]['grads'])
