@@ -59,23 +59,28 @@ def event_time_ms(fn, iters, stream):
 
 
 def roofline_em_pass(device):
-    """HBM-bound kernel of the EM loop: the fused E-step/M-step pass (em_pass_kernel).
+    """HBM-bound kernel of the EM loop: the fused E-step/M-step pass (em_pass_kernel), at the training shape
+    (Omniglot 20-way: latency-bound, 10 MB per launch) and at the evaluation-sweep shape of the feature models
+    (256 episodes x 75 queries x 256 MC samples, 5-way: 1.26 GB per launch).
     Algorithmic bytes per launch = B*(N*D*4 + K*(2D+2)*4)  (SURVEY.md §8d)."""
     from cmvae_amd import ops
-    B, N, K, D = B_PER_GPU, SAMPLE * MC, WAY, 64
-    g = torch.Generator(device='cpu').manual_seed(1)
-    z = torch.randn(B, N, D, generator=g).to(device)
-    mu = torch.randn(B, K, D, generator=g).to(device)
-    logw = torch.randn(B, K, generator=g).to(device)
-    ws, _ = ops.em_pass(z, mu, logw)
-    stream = torch.cuda.current_stream()
-    ms = event_time_ms(lambda: ops.em_pass(z, mu, logw, ws), 200, stream)
-    alg_bytes = B * (N * D * 4 + K * (2 * D + 2) * 4)
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
-    return {'kernel': 'em_pass_kernel', 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-            'launch_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes,
-            'note': 'back-to-back launches from Python: includes host launch gaps'}
+    out = []
+    for tag, (B, N, K) in (('train O20', (B_PER_GPU, SAMPLE * MC, WAY)), ('eval sweep 5-way', (256, 75 * 256, 5))):
+        g = torch.Generator(device='cpu').manual_seed(1)
+        z = torch.randn(B, N, 64, generator=g).to(device)
+        mu = torch.randn(B, K, 64, generator=g).to(device)
+        logw = torch.randn(B, K, generator=g).to(device)
+        ws, _ = ops.em_pass(z, mu, logw)
+        stream = torch.cuda.current_stream()
+        ms = event_time_ms(lambda: ops.em_pass(z, mu, logw, ws), 50, stream)
+        alg_bytes = B * (N * 64 * 4 + K * (2 * 64 + 2) * 4)
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        out.append({'kernel': 'em_pass_kernel', 'shape': tag, 'bound': 'hbm', 'achieved': round(achieved, 1),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'launch_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes,
+                    'note': 'back-to-back launches from Python: includes host launch gaps'})
+        del z
+    return out
 
 
 def useful_flops(g, ncb):
@@ -285,7 +290,7 @@ def main():
             'final_losses': {'rec': losses[0], 'kl': losses[1], 'h_aug': losses[2]},
         }
         out['roofline'] = roof
-        out['roofline_other'] = [roofline_em_pass(device)]
+        out['roofline_other'] = roofline_em_pass(device)
         note('roofline measurements done; starting cpu baseline')
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '16')))

@@ -222,21 +222,8 @@ struct PassArgs {
     int N, K, tiles_per_block, nblk;
 };
 
-// Load a 64-row tile of z into LDS (coalesced float4), rows >= N zero-filled.
-__device__ __forceinline__ void load_tile(const float* __restrict__ zb, int row0, int N, float* zs) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int e = tid + 256 * it;       // float4 index within the tile: 64 rows x 16
-        const int r = e >> 4, q = e & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < N) v = reinterpret_cast<const float4*>(zb + (size_t)(row0 + r) * D)[q];
-        *reinterpret_cast<float4*>(&zs[r * ZS_LD + 4 * q]) = v;
-    }
-}
-
-// responsibilities of a tile: on entry lls[row][k] holds the joint log-likelihoods; on exit
-// r (optionally scaled).  4 threads per row.  Returns the row's logsumexp to the caller.
+// responsibilities of a 64-row tile: on entry lls[row][k] holds the joint log-likelihoods; on exit the
+// posteriors.  4 threads per row.  Returns the row's logsumexp to the caller.  (posterior_argmax_kernel)
 template <int KQ>
 __device__ __forceinline__ float softmax_rows(float* lls, int K) {
     constexpr int KP = 4 * KQ;
@@ -266,128 +253,221 @@ __device__ __forceinline__ float softmax_rows(float* lls, int K) {
     return lse;
 }
 
-template <int KQ>
-__global__ __launch_bounds__(256) void em_pass_kernel(PassArgs a) {
-    constexpr int KP = 4 * KQ;
-    constexpr int LD = KP + 1;
-    __shared__ __align__(16) float zs[TR * ZS_LD];
-    __shared__ __align__(16) float mus[KP * D];
-    __shared__ float lls[TR * LD];
+// ------------------------------------------------------------------ fused E-step / M-step pass
+// One workgroup streams 128-row tiles of one episode's latents (32 KB each) through LDS:
+//   E-step   2 threads per row (row in registers), each ceil(K/2) components against the LDS-resident means;
+//            the pair's softmax is two shuffles; responsibilities go to LDS as R[row][k] (optionally scaled by g);
+//   M-step   S1[k][d] += R^T Z (and S2 with Z*Z) on v_mfma_f32_32x32x2_f32: the contraction runs over the rows
+//            of the tile, wave = (row half, d half); K <= 32 fills the M side of the tile exactly;
+//   N_k      accumulated in the E-step threads' registers, reduced once at the end.
+// The next tile's rows are fetched into registers while the current one is processed.  Per-block partials, reduced
+// by em_finalize / the reduce kernels in a fixed order: no float atomics, results reproducible.
+constexpr int TRP = 128;      // rows per tile
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// K <= 16: M-step on v_mfma_f32_16x16x4_f32 (16 components x 16 latent dims per accumulator, wave = 16-column
+// block of d), R pitch 16; K <= 32: v_mfma_f32_32x32x2_f32 (wave = (row half, d half)), R pitch 33.
+template <int KH, bool MOM2, bool DZ>     // KH: components per E-step thread (K <= 2*KH); second moments; dz output
+__global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(PassArgs a) {
+    constexpr int KP = 2 * KH;
+    constexpr bool SMALLK = KH <= 8;
+    constexpr int RL = SMALLK ? 16 : 33;
+    __shared__ __align__(16) float zs[TRP * ZS_LD];
+    constexpr int MP = D;                            // pitch of the means (padding it to 68 measured slower)
+    __shared__ __align__(16) float mus[KP * MP];
+    __shared__ float Rs[TRP * RL];
     __shared__ float lws[KP];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.y, blk = blockIdx.x;
     const int N = a.N, K = a.K;
     const float* zb = a.z + (size_t)b * N * D;
+    const int erow = tid >> 1, half = tid & 1;      // E-step: 2 threads per row
+    const int i = lane & 31, h = lane >> 5;         // MFMA lane coordinates
+    const int dh = w & 1, rh = w >> 1;              // wave = (d half, row half)
+    const int q = tid & 15, lr = tid >> 4;          // tile load: 16 lanes per row, 16 rows per pass
 
     if (a.mu) {
-        for (int e = tid; e < KP * D; e += 256) mus[e] = (e < K * D) ? a.mu[(size_t)b * K * D + e] : 0.f;
+        for (int e = tid; e < KP * D; e += 256) mus[(e >> 6) * MP + (e & 63)] = (e < K * D) ? a.mu[(size_t)b * K * D + e] : 0.f;
         if (tid < KP) lws[tid] = (tid < K) ? a.logw[b * K + tid] : -INFINITY;
     }
+    for (int e = tid; e < TRP * RL; e += 256) Rs[e] = 0.f;       // columns >= K stay zero for the MFMA
     const bool mstep = a.part_S1 != nullptr;
-    const bool mom2 = a.part_S2 != nullptr;
-    float s1[KQ], s2[KQ];
+    constexpr bool mom2 = MOM2;
+    floatx16 acc1 = {}, acc2 = {};
+    floatx4 q1 = {0.f, 0.f, 0.f, 0.f}, q2 = {0.f, 0.f, 0.f, 0.f};
+    float nk[KH];
 #pragma unroll
-    for (int j = 0; j < KQ; ++j) s1[j] = s2[j] = 0.f;
-    float nk = 0.f;   // thread k < KP accumulates N_k
+    for (int j = 0; j < KH; ++j) nk[j] = 0.f;
+    float mud[DZ ? KP : 1];                          // dz path: this lane's column of the means
+    if (DZ) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) mud[k] = (k < K) ? a.mu[((size_t)b * K + k) * D + lane] : 0.f;
+    }
 
+    const int tile0 = blk * a.tiles_per_block;
+    float4 pre[8];
+    auto fetch = [&](int row0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = row0 + lr + 16 * e;
+            pre[e] = reinterpret_cast<const float4*>(zb + (size_t)(r < N ? r : 0) * D)[q];
+            if (r >= N) pre[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (tile0 * TRP < N) fetch(tile0 * TRP);
     for (int t = 0; t < a.tiles_per_block; ++t) {
-        const int row0 = (blk * a.tiles_per_block + t) * TR;
+        const int row0 = (tile0 + t) * TRP;
         if (row0 >= N) break;          // uniform across the block
-        __syncthreads();               // previous tile fully consumed (also covers mus/lws stores)
-        load_tile(zb, row0, N, zs);
+        __syncthreads();               // previous tile fully consumed (also covers mus / lws / Rs stores)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<float4*>(&zs[(lr + 16 * e) * ZS_LD + 4 * q]) = pre[e];
         __syncthreads();
-        const int row = lane;          // E-step: lane = row, wave = component residue
-        const bool valid = row0 + row < N;
+        if (t + 1 < a.tiles_per_block && row0 + TRP < N) fetch(row0 + TRP);
+        const bool valid = row0 + erow < N;
+        float r[KH];
         if (a.labels) {
-            const int64_t lab = valid ? a.labels[(size_t)b * N + row0 + row] : -1;
+            const int64_t lab = valid ? a.labels[(size_t)b * N + row0 + erow] : -1;
 #pragma unroll
-            for (int j = 0; j < KQ; ++j) {
-                const int k = w + 4 * j;
-                lls[row * LD + k] = (lab == k) ? 1.f : 0.f;
-            }
-            __syncthreads();
+            for (int j = 0; j < KH; ++j) r[j] = (lab == half + 2 * j) ? 1.f : 0.f;
         } else {
-            float zr[D];
+            // squared distances, the row taken in two halves of 32 dims to keep it in 32 registers
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(&zs[row * ZS_LD + 4 * q]);
-                zr[4 * q] = v.x; zr[4 * q + 1] = v.y; zr[4 * q + 2] = v.z; zr[4 * q + 3] = v.w;
-            }
+            for (int j = 0; j < KH; ++j) r[j] = 0.f;
 #pragma unroll
-            for (int j = 0; j < KQ; ++j) {
-                const int k = w + 4 * j;
-                float acc = 0.f;
+            for (int hf = 0; hf < 2; ++hf) {
+                float zr[32];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float4 m = *reinterpret_cast<const float4*>(&mus[k * D + 4 * q]);
-                    float d0 = zr[4 * q] - m.x, d1 = zr[4 * q + 1] - m.y;
-                    float d2 = zr[4 * q + 2] - m.z, d3 = zr[4 * q + 3] - m.w;
-                    acc = fmaf(d0, d0, acc);
-                    acc = fmaf(d1, d1, acc);
-                    acc = fmaf(d2, d2, acc);
-                    acc = fmaf(d3, d3, acc);
+                for (int c = 0; c < 8; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(&zs[erow * ZS_LD + 32 * hf + 4 * c]);
+                    zr[4 * c] = v.x; zr[4 * c + 1] = v.y; zr[4 * c + 2] = v.z; zr[4 * c + 3] = v.w;
                 }
-                lls[row * LD + k] = fmaf(-0.5f, acc, D * LOG_NORM) + lws[k];
-            }
-            __syncthreads();
-            const float lse = softmax_rows<KQ>(lls, K);
-            const int srow = tid >> 2;
-            if (a.lse && (tid & 3) == 0 && row0 + srow < N) a.lse[(size_t)b * N + row0 + srow] = lse;
-            {
-                // zero (or g-scale) the responsibilities; padded rows contribute nothing
-                const bool sv = row0 + srow < N;
-                const float gs = !sv ? 0.f : (a.g ? a.g[(size_t)b * N + row0 + srow] : 1.f);
-                if (gs != 1.f) {
 #pragma unroll
-                    for (int j = 0; j < KQ; ++j) lls[srow * LD + (tid & 3) + 4 * j] *= gs;
+                for (int j = 0; j < KH; ++j) {
+                    const int k = half + 2 * j;
+                    float acc = r[j];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float4 m = *reinterpret_cast<const float4*>(&mus[k * MP + 32 * hf + 4 * c]);
+                        const float d0 = zr[4 * c] - m.x, d1 = zr[4 * c + 1] - m.y;
+                        const float d2 = zr[4 * c + 2] - m.z, d3 = zr[4 * c + 3] - m.w;
+                        acc = fmaf(d0, d0, acc);
+                        acc = fmaf(d1, d1, acc);
+                        acc = fmaf(d2, d2, acc);
+                        acc = fmaf(d3, d3, acc);
+                    }
+                    r[j] = acc;
                 }
             }
-            __syncthreads();
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < KH; ++j) {
+                r[j] = fmaf(-0.5f, r[j], D * LOG_NORM) + lws[half + 2 * j];        // -inf for k >= K
+                mx = fmaxf(mx, r[j]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < KH; ++j) sum += expf(r[j] - mx);
+            sum += __shfl_xor(sum, 1);
+            const float lse = mx + logf(sum);
+            if (a.lse && half == 0 && valid) a.lse[(size_t)b * N + row0 + erow] = lse;
+            const float gs = !valid ? 0.f : (a.g ? a.g[(size_t)b * N + row0 + erow] : 1.f);
+#pragma unroll
+            for (int j = 0; j < KH; ++j) r[j] = expf(r[j] - lse) * gs;
         }
-        // N_k partial
-        if (a.part_N && tid < KP) {
-            float acc = 0.f;
-            for (int r = 0; r < TR; ++r) acc += lls[r * LD + tid];
-            nk += acc;
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            Rs[erow * RL + half + 2 * j] = r[j];
+            nk[j] += r[j];
         }
+        __syncthreads();
         if (mstep) {
-            // thread: d = lane, components k = w + 4j
-            for (int r = 0; r < TR; ++r) {
-                const float zv = zs[r * ZS_LD + lane];
-                const float zv2 = zv * zv;
-#pragma unroll
-                for (int j = 0; j < KQ; ++j) {
-                    const float rv = lls[r * LD + w + 4 * j];
-                    s1[j] = fmaf(rv, zv, s1[j]);
-                    if (mom2) s2[j] = fmaf(rv, zv2, s2[j]);
+            if (SMALLK) {
+                // A[k = lane&15][row = 4s + (lane>>4)], B[row][d = 16w + (lane&15)]; operands read one step ahead
+                const int i16 = lane & 15, g4 = lane >> 4;
+                const float* rp = &Rs[g4 * RL + i16];
+                const float* zp = &zs[g4 * ZS_LD + 16 * w + i16];
+                float av = rp[0], zv = zp[0];
+#pragma unroll 8
+                for (int s4 = 0; s4 < TRP / 4; ++s4) {
+                    float an = av, zn = zv;
+                    if (s4 + 1 < TRP / 4) { an = rp[(4 * s4 + 4) * RL]; zn = zp[(4 * s4 + 4) * ZS_LD]; }
+                    q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zv, q1, 0, 0, 0);
+                    if (mom2) q2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zv * zv, q2, 0, 0, 0);
+                    av = an; zv = zn;
+                }
+            } else {
+                const float* rp = &Rs[(64 * rh + h) * RL + i];
+                const float* zp = &zs[(64 * rh + h) * ZS_LD + 32 * dh + i];
+                float av = rp[0], zv = zp[0];
+#pragma unroll 8
+                for (int s2 = 0; s2 < 32; ++s2) {
+                    float an = av, zn = zv;
+                    if (s2 + 1 < 32) { an = rp[(2 * s2 + 2) * RL]; zn = zp[(2 * s2 + 2) * ZS_LD]; }
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, zv, acc1, 0, 0, 0);
+                    if (mom2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, zv * zv, acc2, 0, 0, 0);
+                    av = an; zv = zn;
                 }
             }
         }
-        if (a.dz) {
-            // dz[row][d] = sum_k w_k mu_k[d] - z[d] * sum_k w_k   (w = g * r)
-            for (int rr = 0; rr < 16; ++rr) {
-                const int r = 16 * w + rr;
-                if (row0 + r >= N) break;
+        if (DZ) {
+            // dz[row][d] = sum_k w_k mu_k[d] - z[d] * sum_k w_k   (w = g * r); wave w owns rows 32w .. 32w+31
+            for (int rr = 0; rr < 32; ++rr) {
+                const int rw = 32 * w + rr;
+                if (row0 + rw >= N) break;
                 float acc = 0.f, ws = 0.f;
-                for (int k = 0; k < K; ++k) {
-                    const float rv = lls[r * LD + k];
-                    acc = fmaf(rv, mus[k * D + lane], acc);
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const float rv = Rs[rw * RL + k];
+                    acc = fmaf(rv, mud[k], acc);
                     ws += rv;
                 }
-                a.dz[((size_t)b * N + row0 + r) * D + lane] = acc - zs[r * ZS_LD + lane] * ws;
+                a.dz[((size_t)b * N + row0 + rw) * D + lane] = acc - zs[rw * ZS_LD + lane] * ws;
             }
         }
     }
-    if (a.part_N && tid < 32) a.part_N[((size_t)b * a.nblk + blk) * 32 + tid] = (tid < KP) ? nk : 0.f;
-    if (mstep) {
+    // ---- block partials
+    __syncthreads();
+    float* red = zs;                                  // reuse the tile: needs 2*32*64 (+ 2*32*64) + 128*KP floats
+    if (a.part_N) {
+        float* rn = red + 2 * 2 * 32 * 64;            // [128][KP]
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-            const int k = w + 4 * j;
-            if (k < K) {
-                const size_t o = (((size_t)b * a.nblk + blk) * K + k) * D + lane;
-                a.part_S1[o] = s1[j];
-                if (mom2) a.part_S2[o] = s2[j];
+        for (int j = 0; j < KH; ++j) rn[erow * KP + half + 2 * j] = nk[j];
+    }
+    if (mstep) {
+        if (SMALLK) {
+            // accumulator: row k = 4*(lane>>4) + reg, column d = 16w + (lane&15); the second row-half slab stays zero
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int k = 4 * (lane >> 4) + reg, d = 16 * w + (lane & 15);
+                red[k * 64 + d] = q1[reg];
+                red[(32 + k) * 64 + d] = 0.f;
+                if (mom2) { red[2 * 32 * 64 + k * 64 + d] = q2[reg]; red[2 * 32 * 64 + (32 + k) * 64 + d] = 0.f; }
             }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int k = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                red[(rh * 32 + k) * 64 + 32 * dh + i] = acc1[reg];
+                if (mom2) red[2 * 32 * 64 + (rh * 32 + k) * 64 + 32 * dh + i] = acc2[reg];
+            }
+        }
+    }
+    __syncthreads();
+    if (a.part_N && tid < 32) {
+        float s = 0.f;
+        if (tid < KP) {
+            const float* rn = red + 2 * 2 * 32 * 64;
+            for (int r2 = 0; r2 < TRP; ++r2) s += rn[r2 * KP + tid];
+        }
+        a.part_N[((size_t)b * a.nblk + blk) * 32 + tid] = s;
+    }
+    if (mstep) {
+        for (int e = tid; e < K * D; e += 256) {
+            const size_t o = ((size_t)b * a.nblk + blk) * K * D + e;
+            a.part_S1[o] = red[e] + red[32 * 64 + e];
+            if (mom2) a.part_S2[o] = red[2 * 32 * 64 + e] + red[3 * 32 * 64 + e];
         }
     }
 }
@@ -645,7 +725,7 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(const float* __re
 
 // ------------------------------------------------------------------ host side
 static int pick_tiles_per_block(int B, int N) {
-    const int tiles_ep = (N + TR - 1) / TR;
+    const int tiles_ep = (N + TRP - 1) / TRP;
     const long total = (long)tiles_ep * B;
     int tpb = (int)(total / 256);
     if (tpb > tiles_ep) tpb = tiles_ep;
@@ -653,7 +733,7 @@ static int pick_tiles_per_block(int B, int N) {
     return tpb;
 }
 static int nblk_for(int N, int tpb) {
-    const int tiles_ep = (N + TR - 1) / TR;
+    const int tiles_ep = (N + TRP - 1) / TRP;
     return (tiles_ep + tpb - 1) / tpb;
 }
 
@@ -673,12 +753,28 @@ static int dispatch_kq(int K, F&& f) {
     return set_error("component count K=%d outside [1,%d]", K, CMVAE_KMAX);
 }
 
+template <int KH>
+static void launch_pass_kh(const PassArgs& a, int B, hipStream_t st) {
+    const dim3 grid(a.nblk, B);
+    if (a.dz) hipLaunchKernelGGL((em_pass_kernel<KH, false, true>), grid, dim3(256), 0, st, a);
+    else if (a.part_S2) hipLaunchKernelGGL((em_pass_kernel<KH, true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((em_pass_kernel<KH, false, false>), grid, dim3(256), 0, st, a);
+}
+
 static int launch_pass(const PassArgs& a, int B, hipStream_t st) {
-    return dispatch_kq(a.K, [&](auto kq) {
-        constexpr int KQ = decltype(kq)::value;
-        hipLaunchKernelGGL(em_pass_kernel<KQ>, dim3(a.nblk, B), dim3(256), 0, st, a);
-        return check_launch("em_pass_kernel");
-    });
+    if (a.dz && a.part_S2) return set_error("em_pass: dz and second moments are not produced together");
+#define CMVAE_PASS(KH) launch_pass_kh<KH>(a, B, st); break
+    switch ((a.K + 1) / 2) {
+        case 1: CMVAE_PASS(1); case 2: CMVAE_PASS(2); case 3: CMVAE_PASS(3); case 4: CMVAE_PASS(4);
+        case 5: CMVAE_PASS(5); case 6: CMVAE_PASS(6); case 7: CMVAE_PASS(7); case 8: CMVAE_PASS(8);
+        case 9: case 10: CMVAE_PASS(10);
+        case 11: case 12: CMVAE_PASS(12);
+        case 13: case 14: CMVAE_PASS(14);
+        case 15: case 16: CMVAE_PASS(16);
+        default: return set_error("component count K=%d outside [1,%d]", a.K, CMVAE_KMAX);
+    }
+#undef CMVAE_PASS
+    return check_launch("em_pass_kernel");
 }
 
 static int check_causal(const cmvae_causal* c) {
