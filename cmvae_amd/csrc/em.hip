@@ -7,6 +7,9 @@
 // part_N [B,nblk,32], part_S1/part_S2 [B,nblk,K,64] are reduced in a fixed order by the
 // finalize kernels (no float atomics: results are run-to-run reproducible).
 #include "common.h"
+#ifndef CMVAE_ABLATE_EM
+#define CMVAE_ABLATE_EM 0      // profiling builds only: 1 = no distance loops, 2 = no M-step MFMA
+#endif
 #include <type_traits>
 
 namespace cmvae {
@@ -272,7 +275,7 @@ template <int KH, bool MOM2, bool DZ>     // KH: components per E-step thread (K
 __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(PassArgs a) {
     constexpr int KP = 2 * KH;
     constexpr bool SMALLK = KH <= 8;
-    constexpr int RL = SMALLK ? 16 : 33;
+    constexpr int RL = SMALLK ? 20 : 33;
     __shared__ __align__(16) float zs[TRP * ZS_LD];
     constexpr int MP = D;                            // pitch of the means (padding it to 68 measured slower)
     __shared__ __align__(16) float mus[KP * MP];
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
             // squared distances, the row taken in two halves of 32 dims to keep it in 32 registers
 #pragma unroll
             for (int j = 0; j < KH; ++j) r[j] = 0.f;
+#if !(CMVAE_ABLATE_EM & 1)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 float zr[32];
@@ -359,6 +363,7 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
                     r[j] = acc;
                 }
             }
+#endif
             float mx = -INFINITY;
 #pragma unroll
             for (int j = 0; j < KH; ++j) {
@@ -382,17 +387,23 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
             nk[j] += r[j];
         }
         __syncthreads();
-        if (mstep) {
+        if (mstep && !(CMVAE_ABLATE_EM & 2)) {
             if (SMALLK) {
-                // A[k = lane&15][row = 4s + (lane>>4)], B[row][d = 16w + (lane&15)]; operands read one step ahead
+                // A[k = lane&15][row], B[row][d = 16w + (lane&15)] with row = 16*(s>>2) + 4*(lane>>4) + (s&3): the four
+                // lane groups sit 4 rows apart, which with pitches 20 and 68 puts them in disjoint banks;
+                // operands are read one step ahead
                 const int i16 = lane & 15, g4 = lane >> 4;
-                const float* rp = &Rs[g4 * RL + i16];
-                const float* zp = &zs[g4 * ZS_LD + 16 * w + i16];
+                const float* rp = &Rs[4 * g4 * RL + i16];
+                const float* zp = &zs[4 * g4 * ZS_LD + 16 * w + i16];
                 float av = rp[0], zv = zp[0];
 #pragma unroll 8
                 for (int s4 = 0; s4 < TRP / 4; ++s4) {
                     float an = av, zn = zv;
-                    if (s4 + 1 < TRP / 4) { an = rp[(4 * s4 + 4) * RL]; zn = zp[(4 * s4 + 4) * ZS_LD]; }
+                    if (s4 + 1 < TRP / 4) {
+                        const int rn = 16 * ((s4 + 1) >> 2) + ((s4 + 1) & 3);
+                        an = rp[rn * RL];
+                        zn = zp[rn * ZS_LD];
+                    }
                     q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zv, q1, 0, 0, 0);
                     if (mom2) q2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, zv * zv, q2, 0, 0, 0);
                     av = an; zv = zn;
