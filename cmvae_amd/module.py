@@ -124,9 +124,9 @@ class LocallyConnected(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
-    def forward(self, x):                      # x [n,d,m1]
-        out = torch.einsum('ndm,dmo->ndo', x, self.weight)
-        return out if self.bias is None else out + self.bias
+    def forward(self, x):
+        raise RuntimeError('LocallyConnected is a parameter container: CausalEncoder.forward runs the ELU + locally '
+                           'connected tail in cmvae_causal_lc_fwd / cmvae_causal_rows')
 
 
 class CausalEncoder(nn.Module):
