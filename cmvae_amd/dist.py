@@ -95,24 +95,44 @@ def gather_episode_values(values, local_batch):
 
 
 class FlatGrads:
-    """All parameter gradients as views into one flat fp32 buffer (4.56 MB for Omniglot), so the
-    step's gradient exchange is a single all-reduce with no pack/unpack copies."""
+    """All parameter gradients in one flat fp32 buffer (4.56 MB for Omniglot): the step's gradient exchange is a
+    single all-reduce and the optimizer a single kernel over it.
+
+    Between `zero()` and `pack()` the parameters carry no `.grad`, so autograd hands every gradient over as it
+    is produced (no per-parameter accumulation kernel); `pack()` — called by `allreduce()` — gathers them into
+    the flat buffer with one multi-tensor copy and points every `.grad` at its slice."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros((n + 3) // 4 * 4, dtype=ref.dtype, device=ref.device)     # padded for float4 kernels
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+            p.grad = self.views[-1]
 
     def zero(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def allreduce(self):
-        """Mean over ranks.  Valid because every loss term is a mean over equal-sized shards."""
+        """Gather the gradients, then mean over ranks (every loss term is a mean over equal-sized shards)."""
+        self.pack()
         ws = world_size()
         if ws > 1:
             tdist.all_reduce(self.flat, op=tdist.ReduceOp.SUM)

@@ -73,6 +73,7 @@ def test_two_rank_step_equals_single_process():
     flat.zero()
     y = net(_data())
     (y ** 2).mean().backward()
+    flat.pack()
     got_y = torch.cat([out[0]['y'], out[1]['y']], 0)
     assert torch.allclose(got_y, y.detach(), atol=1e-5)
     for r in range(world):

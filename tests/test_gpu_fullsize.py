@@ -127,6 +127,7 @@ def test_full_size_training_step_is_reproducible(device):
         flat.zero()
         _, rec, kl, h_aug, h = model(X, 0.1, 0.1, 1e-4, eps=eps, init_idx=idx)
         (rec + kl + h_aug).backward()
+        flat.pack()
         outs.append((rec.detach().clone(), kl.detach().clone(), h_aug.detach().clone(), flat.flat.clone()))
     # (training mode normalises with batch statistics: the running-statistics update between the steps is inert)
     for a, b in zip(outs[0], outs[1]):
