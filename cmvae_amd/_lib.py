@@ -113,6 +113,10 @@ def _load():
         raise ImportError(
             'cmvae_amd: %s not found. Build it with `make -C cmvae_amd/csrc` (or '
             '`python -c "import __graft_entry__ as g; g.build()"`). There is no fallback path.' % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64: import it first so that the library below binds to the SAME HIP
+    # runtime as the tensors it is handed (loaded the other way round, the process ends up with two runtimes and
+    # every launch from here fails with "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly

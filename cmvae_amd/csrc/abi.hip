@@ -17,4 +17,5 @@ int set_error(const char* fmt, ...) {
 }  // namespace cmvae
 
 extern "C" const char* cmvae_last_error(void) { return cmvae::g_last_error.c_str(); }
-extern "C" int cmvae_abi_version(void) { return 1; }
+extern "C" int cmvae_abi_version(void) {
+    cmvae::clear_stale_error(); return 1; }

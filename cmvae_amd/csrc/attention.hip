@@ -228,6 +228,7 @@ using namespace cmvae;
 
 extern "C" int cmvae_attention_fwd(const float* Q, const float* K, const float* V, int B, int S, int heads,
                                    float scale, float* O, float* lse, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(Q && K && V && O && lse, "cmvae_attention_fwd: NULL argument");
     if (int e = check_attn("cmvae_attention_fwd", B, S, heads)) return e;
     const int SP = (S + 3) & ~3;
@@ -241,6 +242,7 @@ extern "C" int cmvae_attention_fwd(const float* Q, const float* K, const float* 
 extern "C" int cmvae_attention_bwd(const float* Q, const float* K, const float* V, const float* lse, const float* dO,
                                    int B, int S, int heads, float scale, float* dQ, float* dK, float* dV,
                                    float* delta, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(Q && K && V && lse && dO && dQ && dK && dV && delta, "cmvae_attention_bwd: NULL argument");
     if (int e = check_attn("cmvae_attention_bwd", B, S, heads)) return e;
     const int SP = (S + 3) & ~3;

@@ -15,6 +15,10 @@ constexpr float LOG_NORM = -0.91893853320467274178f;   // -0.5*log(2*pi)
 
 int set_error(const char* fmt, ...);
 
+// hipGetLastError reports the last error of ANY earlier runtime call of this thread (the host framework's device
+// probing included); every entry point drops that stale state first so check_launch speaks for its own launches.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error("%s: %s", what, hipGetErrorString(e));

@@ -504,11 +504,13 @@ static int wgrad_grid(int rows_total) {
     return ntiles < 512 ? (ntiles > 0 ? ntiles : 1) : 512;
 }
 
-extern "C" int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks) { return gemm_grid(rows_total, n_col_blocks); }
+extern "C" int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks) {
+    cmvae::clear_stale_error(); return gemm_grid(rows_total, n_col_blocks); }
 
 extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, const float* Wt, const float* bias,
                                const float* a_scale, const float* a_shift, int act, int n_col_blocks, float* out,
                                float* stats_part, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(geom && A && Wt && out, "cmvae_conv_gemm: NULL argument");
     CMVAE_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "cmvae_conv_gemm: scale and shift go together");
     CMVAE_REQUIRE(n_col_blocks >= 1 && act >= 0 && act <= 2, "cmvae_conv_gemm: bad act / column blocks");
@@ -582,6 +584,7 @@ extern "C" int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, con
                                 const float* a_shift, const float* G, int g_pitch, int g_col,
                                 const int64_t* tap_off_host, int64_t s_ci, int64_t s_co, float* dW, float* db,
                                 int accumulate_db, void* workspace, size_t workspace_bytes, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(geom && A && G && tap_off_host && dW && workspace, "cmvae_conv_wgrad: NULL argument");
     CMVAE_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "cmvae_conv_wgrad: scale and shift go together");
     ConvGeom g = to_geom(geom);
@@ -671,6 +674,7 @@ static int check_linear(const char* who, int rows, int in_f, int out_f) {
 
 extern "C" int cmvae_linear_fwd(const float* X, int x_pitch, int rows, int in_f, int out_f, const float* W,
                                 const float* bias, int act, float* Y, int y_pitch, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(X && W && Y, "cmvae_linear_fwd: NULL argument");
     if (int e = check_linear("cmvae_linear_fwd", rows, in_f, out_f)) return e;
     CMVAE_REQUIRE(x_pitch >= in_f && x_pitch % 4 == 0 && y_pitch >= out_f && act >= 0 && act <= 2,
@@ -689,6 +693,7 @@ extern "C" size_t cmvae_linear_bwd_workspace_bytes(int rows, int in_f, int out_f
 extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, const float* dZ, int dz_pitch, int rows,
                                 int in_f, int out_f, float* dX, int dx_pitch, float* dW, float* db, void* workspace,
                                 size_t workspace_bytes, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(X && W && dZ && dW && workspace, "cmvae_linear_bwd: NULL argument");
     if (int e = check_linear("cmvae_linear_bwd", rows, in_f, out_f)) return e;
     CMVAE_REQUIRE(x_pitch >= in_f && x_pitch % 4 == 0 && dz_pitch >= out_f && dz_pitch % 4 == 0 &&

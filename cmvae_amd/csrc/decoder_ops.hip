@@ -463,6 +463,7 @@ static int img_grid(int nimg) { return nimg < 1024 ? (nimg > 0 ? nimg : 1) : 102
 using namespace cmvae;
 
 extern "C" int cmvae_colsum_reduce(const float* part, int nblk, int L, float* out, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(part && out && nblk >= 1 && L >= 1, "cmvae_colsum_reduce: bad arguments");
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((L + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, nblk, L, out);
     return check_launch("colsum_reduce_kernel");
@@ -471,6 +472,7 @@ extern "C" int cmvae_colsum_reduce(const float* part, int nblk, int L, float* ou
 extern "C" int cmvae_bn_finalize(const float* sums, double count, const float* gamma, const float* beta, float eps,
                                  float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                                  float* mean, float* invstd, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && count > 1, "cmvae_bn_finalize: bad arguments");
     CMVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cmvae_bn_finalize: running stats go together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, (float)count, gamma, beta,
@@ -478,11 +480,13 @@ extern "C" int cmvae_bn_finalize(const float* sums, double count, const float* g
     return check_launch("bn_finalize_kernel");
 }
 
-extern "C" int cmvae_rowpass_grid(int64_t rows) { return rowpass_grid(rows); }
+extern "C" int cmvae_rowpass_grid(int64_t rows) {
+    cmvae::clear_stale_error(); return rowpass_grid(rows); }
 
 extern "C" int cmvae_bn_relu_bwd_reduce(const float* d_a, const float* y, const float* scale, const float* shift,
                                         const float* mean, const float* invstd, int64_t rows, int masked, float* part,
                                         void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(d_a && y && scale && shift && mean && invstd && part && rows >= 1, "cmvae_bn_relu_bwd_reduce: bad arguments");
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(rowpass_grid(rows)), dim3(256), 0, (hipStream_t)stream, d_a, y,
                        scale, shift, mean, invstd, (long)rows, masked, part);
@@ -491,6 +495,7 @@ extern "C" int cmvae_bn_relu_bwd_reduce(const float* d_a, const float* y, const 
 
 extern "C" int cmvae_bn_bwd_finalize(const float* sums_local, const float* sums_global, double count, float* c1,
                                      float* c2, float* dgamma, float* dbeta, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(sums_local && sums_global && c1 && c2 && dgamma && dbeta && count >= 1, "cmvae_bn_bwd_finalize: bad arguments");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums_local, sums_global,
                        (float)count, c1, c2, dgamma, dbeta);
@@ -500,18 +505,22 @@ extern "C" int cmvae_bn_bwd_finalize(const float* sums_local, const float* sums_
 extern "C" int cmvae_bn_relu_bwd_apply(const float* d_a, const float* y, const float* scale, const float* shift,
                                        const float* mean, const float* invstd, const float* c1, const float* c2,
                                        int64_t rows, int masked, float* dy, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(d_a && y && scale && shift && mean && invstd && c1 && c2 && dy && rows >= 1, "cmvae_bn_relu_bwd_apply: bad arguments");
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(rowpass_grid(rows)), dim3(256), 0, (hipStream_t)stream, d_a, y,
                        scale, shift, mean, invstd, c1, c2, (long)rows, masked, dy);
     return check_launch("bn_relu_bwd_apply_kernel");
 }
 
-extern "C" int cmvae_dec_out_grid(int nimg) { return img_grid(nimg); }
-extern "C" int cmvae_dec_out_bwd_partial_len(void) { return DEC_BWD_L; }
+extern "C" int cmvae_dec_out_grid(int nimg) {
+    cmvae::clear_stale_error(); return img_grid(nimg); }
+extern "C" int cmvae_dec_out_bwd_partial_len(void) {
+    cmvae::clear_stale_error(); return DEC_BWD_L; }
 
 extern "C" int cmvae_dec_out_fwd(const float* y3, const float* scale, const float* shift, const float* w4,
                                  const float* b4, const float* target, int M, int nimg, float* p_out,
                                  float* loss_part, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(y3 && scale && shift && w4 && b4 && target && p_out && loss_part, "cmvae_dec_out_fwd: NULL tensor");
     CMVAE_REQUIRE(M >= 1 && nimg >= 1 && nimg % M == 0, "cmvae_dec_out_fwd: images must be a multiple of M");
     hipLaunchKernelGGL(dec_out_fwd_kernel, dim3(nimg < 4096 ? nimg : 4096), dim3(256), 0, (hipStream_t)stream, y3, scale,
@@ -522,6 +531,7 @@ extern "C" int cmvae_dec_out_fwd(const float* y3, const float* scale, const floa
 extern "C" int cmvae_dec_out_bwd(const float* y3, const float* scale, const float* shift, const float* mean,
                                  const float* invstd, const float* w4, const float* p, const float* target, int M,
                                  int nimg, const float* g_dev, float gmul, float* dybn, float* part, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(y3 && scale && shift && mean && invstd && w4 && p && target && part, "cmvae_dec_out_bwd: NULL tensor");
     CMVAE_REQUIRE(M >= 1 && nimg >= 1 && nimg % M == 0, "cmvae_dec_out_bwd: images must be a multiple of M");
     const float* none = nullptr;
@@ -534,6 +544,7 @@ extern "C" int cmvae_dec_out_bwd_apply(const float* y3, const float* scale, cons
                                        const float* invstd, const float* w4, const float* p, const float* target,
                                        int M, int nimg, const float* g_dev, float gmul, const float* c1,
                                        const float* c2, float* dy, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(y3 && scale && shift && mean && invstd && w4 && p && target && c1 && c2 && dy,
                   "cmvae_dec_out_bwd_apply: NULL tensor");
     CMVAE_REQUIRE(M >= 1 && nimg >= 1 && nimg % M == 0, "cmvae_dec_out_bwd_apply: images must be a multiple of M");

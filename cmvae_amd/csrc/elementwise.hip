@@ -162,6 +162,7 @@ using namespace cmvae;
 
 extern "C" int cmvae_reparam_logq_fwd(const float* mean, const float* logvar, const float* eps, int rows, int M,
                                       float* z, float* logq, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(mean && logvar && eps && z, "cmvae_reparam_logq_fwd: NULL tensor");
     CMVAE_REQUIRE(rows >= 0 && M > 0, "cmvae_reparam_logq_fwd: bad shape");
     const long total = (long)rows * M;
@@ -175,6 +176,7 @@ extern "C" int cmvae_reparam_logq_fwd(const float* mean, const float* logvar, co
 
 extern "C" int cmvae_reparam_logq_bwd(const float* logvar, const float* eps, const float* gz, const float* glogq,
                                       int rows, int M, float* dmean, float* dlogvar, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(logvar && eps && dmean && dlogvar, "cmvae_reparam_logq_bwd: NULL tensor");
     CMVAE_REQUIRE(rows >= 0 && M > 0, "cmvae_reparam_logq_bwd: bad shape");
     if (rows == 0) return 0;
@@ -184,6 +186,7 @@ extern "C" int cmvae_reparam_logq_bwd(const float* logvar, const float* eps, con
 }
 
 extern "C" int cmvae_expm_trace(const float* A, float* h, float* grad, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(A && h, "cmvae_expm_trace: NULL tensor");
     hipLaunchKernelGGL(expm_trace_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, h, grad);
     return check_launch("expm_trace_kernel");
@@ -293,6 +296,7 @@ static int grid_for(long n, int per_block) {
 }  // namespace cmvae
 
 extern "C" int cmvae_act_bwd(const float* dY, const float* Y, int64_t n, int act, float* dZ, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(dY && Y && dZ && n >= 0 && n % 4 == 0 && (act == 1 || act == 2), "cmvae_act_bwd: bad arguments");
     if (n == 0) return 0;
     const long n4 = n / 4;
@@ -307,6 +311,7 @@ extern "C" int cmvae_act_bwd(const float* dY, const float* Y, int64_t n, int act
 
 extern "C" int cmvae_causal_lc_fwd(const float* x, const float* hid, const float* w2, const float* b2, int rows,
                                    float* eps, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(x && hid && w2 && b2 && eps && rows >= 0, "cmvae_causal_lc_fwd: bad arguments");
     if (rows == 0) return 0;
     const long items = (long)rows * D;
@@ -315,11 +320,14 @@ extern "C" int cmvae_causal_lc_fwd(const float* x, const float* hid, const float
     return check_launch("causal_lc_fwd_kernel");
 }
 
-extern "C" int cmvae_causal_lc_bwd_grid(int rows) { return rows < 1024 ? (rows > 0 ? rows : 1) : 1024; }
-extern "C" int cmvae_causal_lc_bwd_partial_len(void) { return LC_BWD_L; }
+extern "C" int cmvae_causal_lc_bwd_grid(int rows) {
+    cmvae::clear_stale_error(); return rows < 1024 ? (rows > 0 ? rows : 1) : 1024; }
+extern "C" int cmvae_causal_lc_bwd_partial_len(void) {
+    cmvae::clear_stale_error(); return LC_BWD_L; }
 
 extern "C" int cmvae_causal_lc_bwd(const float* d_eps, const float* hid, const float* w2, int rows, float* d_pre,
                                    float* part, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(d_eps && hid && w2 && d_pre && part && rows >= 1, "cmvae_causal_lc_bwd: bad arguments");
     hipLaunchKernelGGL(causal_lc_bwd_kernel, dim3(cmvae_causal_lc_bwd_grid(rows)), dim3(512), 0, (hipStream_t)stream,
                        d_eps, hid, w2, rows, d_pre, part);
@@ -329,6 +337,7 @@ extern "C" int cmvae_causal_lc_bwd(const float* d_eps, const float* hid, const f
 extern "C" int cmvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                                void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && n % 4 == 0 && step >= 1,
                   "cmvae_adam_step: bad arguments (n must be a multiple of 4, step >= 1)");
     if (n == 0) return 0;

@@ -833,6 +833,7 @@ using namespace cmvae;
 
 extern "C" int cmvae_causal_rows(const float* x, int rows, const cmvae_causal* c, const float* pi, const float* tau,
                                  float* eps, float* logw, void* stream) {
+    cmvae::clear_stale_error();
     if (int e = check_causal(c)) return e;
     CMVAE_REQUIRE(x && rows >= 0, "cmvae_causal_rows: bad arguments");
     CMVAE_REQUIRE(!logw || (pi && tau), "cmvae_causal_rows: logw needs pi and tau");
@@ -845,6 +846,7 @@ extern "C" int cmvae_causal_rows(const float* x, int rows, const cmvae_causal* c
 
 extern "C" int cmvae_gram_inverse(const float* logvar, float s0, int nmat, const cmvae_causal* c, float* out,
                                   void* stream) {
+    cmvae::clear_stale_error();
     if (int e = check_causal(c)) return e;
     CMVAE_REQUIRE(out && nmat >= 0, "cmvae_gram_inverse: bad arguments");
     if (nmat == 0) return 0;
@@ -859,6 +861,7 @@ extern "C" size_t cmvae_unsup_prior_workspace_bytes(int B, int N, int K) {
 extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int64_t* init_idx, const cmvae_causal* c,
                                  int iters, int fix_pi, float gamma1, void* workspace, size_t workspace_bytes,
                                  float* pi, float* mu, float* tau, float* logw, void* stream) {
+    cmvae::clear_stale_error();
     if (int e = check_causal(c)) return e;
     CMVAE_REQUIRE(z && init_idx && pi && mu && tau && logw, "cmvae_unsup_prior: NULL tensor");
     CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX && iters >= 0, "cmvae_unsup_prior: bad shape B=%d N=%d K=%d",
@@ -899,6 +902,7 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
 
 extern "C" int cmvae_em_pass(const float* z, const float* mu, const float* logw, int B, int N, int K, void* workspace,
                              size_t workspace_bytes, int* nblk_out, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(z && mu && logw, "cmvae_em_pass: NULL tensor");
     CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_em_pass: bad shape");
     EmWorkspace w = carve(workspace, B, N, 0, K, false);
@@ -919,6 +923,7 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
                                 const cmvae_causal* c, int iters, float gamma1, void* workspace,
                                 size_t workspace_bytes, float* pi, float* mu, float* logvar, float* tau, float* logw,
                                 void* stream) {
+    cmvae::clear_stale_error();
     if (int e = check_causal(c)) return e;
     CMVAE_REQUIRE(uz && sz && y && pi && mu && logvar && tau && logw, "cmvae_semi_prior: NULL tensor");
     CMVAE_REQUIRE(B > 0 && Nu > 0 && Ns > 0 && K >= 1 && K <= CMVAE_KMAX && iters >= 0,
@@ -963,6 +968,7 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
 
 extern "C" int cmvae_posterior_argmax(const float* z, const float* mu, const float* logvar, const float* logw, int B,
                                       int te, int M, int K, int64_t* y_pred, float* post_mean, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(z && mu && logvar && logw && y_pred, "cmvae_posterior_argmax: NULL tensor");
     CMVAE_REQUIRE(B > 0 && te > 0 && M > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_posterior_argmax: bad shape");
     const int ipb = M >= TR ? 1 : TR / M;
@@ -983,6 +989,7 @@ extern "C" size_t cmvae_mixture_workspace_bytes(int B, int N, int K) {
 
 extern "C" int cmvae_mixture_loglik_fwd(const float* z, const float* mu, const float* logw, int B, int N, int K,
                                         float* lse, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(z && mu && logw && lse, "cmvae_mixture_loglik_fwd: NULL tensor");
     CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_mixture_loglik_fwd: bad shape");
     PassArgs p{};
@@ -994,6 +1001,7 @@ extern "C" int cmvae_mixture_loglik_fwd(const float* z, const float* mu, const f
 extern "C" int cmvae_mixture_loglik_bwd(const float* z, const float* mu, const float* logw, const float* g, int B,
                                         int N, int K, void* workspace, size_t workspace_bytes, float* dz, float* dlogw,
                                         void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(z && mu && logw && g && dz && dlogw, "cmvae_mixture_loglik_bwd: NULL tensor");
     CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_mixture_loglik_bwd: bad shape");
     CMVAE_REQUIRE(workspace && workspace_bytes >= cmvae_mixture_workspace_bytes(B, N, K),

@@ -231,6 +231,7 @@ using namespace cmvae;
 
 extern "C" int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* b, int n, int H, int W, float* y,
                                    float* stats_part, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(x && w && b && y && n >= 1 && H >= 1 && W >= 1 && H <= 32 && W <= 32,
                   "cmvae_enc_conv1_fwd: bad arguments (images up to 32x32)");
     const long rows = (long)n * H * W;
@@ -240,6 +241,7 @@ extern "C" int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* 
 }
 
 extern "C" int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, float* part, void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(x && dy && part && n >= 1 && H >= 1 && W >= 1, "cmvae_enc_conv1_wgrad: bad arguments");
     const long rows = (long)n * H * W;
     hipLaunchKernelGGL(enc_conv1_wgrad_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, dy, H, W, rows,
@@ -249,6 +251,7 @@ extern "C" int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int
 
 extern "C" int cmvae_pool_fwd(const float* y, const float* scale, const float* shift, int n, int H, int W, float* out,
                               void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(y && scale && shift && out && n >= 1 && H >= 1 && W >= 1, "cmvae_pool_fwd: bad arguments");
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long orows = (long)n * Ho * Wo;
@@ -260,6 +263,7 @@ extern "C" int cmvae_pool_fwd(const float* y, const float* scale, const float* s
 extern "C" int cmvae_pool_bwd(const float* d_pool, const float* y, const float* scale, const float* shift,
                               const float* mean, const float* invstd, int n, int H, int W, float* dybn, float* part,
                               void* stream) {
+    cmvae::clear_stale_error();
     CMVAE_REQUIRE(d_pool && y && scale && shift && mean && invstd && dybn && part && n >= 1, "cmvae_pool_bwd: bad arguments");
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const long orows = (long)n * Ho * Wo;

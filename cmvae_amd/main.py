@@ -56,11 +56,13 @@ def main(argv=None):
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
-    if not torch.cuda.is_available():
-        raise SystemExit('cmvae_amd needs an MI355X GPU: there is no CPU path')
     local = int(os.environ.get('LOCAL_RANK', args.gpu_id))
     args.device = torch.device('cuda', local)
-    torch.cuda.set_device(args.device)
+    try:
+        torch.cuda.set_device(args.device)
+        torch.zeros(1, device=args.device)          # create the device context before the HIP library is loaded
+    except Exception as e:
+        raise SystemExit('cmvae_amd needs an MI355X GPU (there is no CPU path): %s' % e)
     os.makedirs(args.save_dir, exist_ok=True)
     from .trainer import Trainer
     return Trainer(args, ns.variant).train()

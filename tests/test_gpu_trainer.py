@@ -60,3 +60,17 @@ def test_feature_trainers_run(tmp_path, variant):
     assert tr.model.linear == (variant == 'mimgnet')
     out = tr.train()
     assert all(np.isfinite(m) for m, _ in out.values())
+
+
+def test_cli_entry_point_in_a_fresh_process(tmp_path):
+    """`python omniglot/main.py ...` (the reference's command line): imports the package before torch, which must
+    still bind the HIP library to PyTorch's runtime (cmvae_amd/_lib.py)."""
+    d = _make(tmp_path, 'omniglot')
+    cmd = [sys.executable, os.path.join(ROOT, 'omniglot', 'main.py'), '--data-dir', d, '--save-dir', str(tmp_path / 'cli'),
+           '--train-iters', '4', '--freq-iters', '2', '--eval-episodes', '4', '--way', '5', '--sample-size', '20',
+           '--batch-size', '2', '--query', '3', '--train-mc-sample-size', '4', '--test-mc-sample-size', '4',
+           '--unsupervised-em-iters', '3', '--semisupervised-em-iters', '3']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert '5shot Final Test Accuracy' in r.stdout
+    assert os.path.exists(str(tmp_path / 'cli' / 'train_log.jsonl'))
