@@ -292,6 +292,155 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
     }
 }
 
+// ---------------------------------------------------------------------------- forward, direct-operand variant
+// For launches without the folded BatchNorm (data gradients, encoder convs, Linear): a lane owns ONE row of the
+// tile and loads its operand directly in MFMA fragment layout (8 x 16 B: channels 8kk + 4h .. +3), one step ahead.
+// The operand never passes through LDS: no staging stores, no A-fragment reads, one row decode per lane, and the
+// two barriers of a step only guard the 16 KB weight tile.
+template <int ACT, bool LINEAR>
+__global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, const float* __restrict__ A,
+                                                                  const float* __restrict__ Wt,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ out,
+                                                                  float* __restrict__ stats_part) {
+    __shared__ __align__(16) float Ws[64 * LDA];
+    __shared__ int opix[2][BM];
+    __shared__ float red[4 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int q = tid & 15, rb = tid >> 4;
+    const int nb = blockIdx.y;
+    const float* Wn = Wt + nb * g.w_nblk_stride + (long)rb * g.w_pitch + 4 * q;
+    const long w16 = 16L * g.w_pitch;
+    const int ntiles = (g.rows_total + BM - 1) / BM;
+    const int nsteps = ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * g.ntaps;
+    const RowDecoder dec(g);
+    float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
+    const float b0 = bias ? bias[nb * 64 + i] : 0.f;
+    const float b1 = bias ? bias[nb * 64 + 32 + i] : 0.f;
+
+    RowInfo ri;
+    float4 ra[8], rw0, rw1, rw2, rw3;
+    int ltile = blockIdx.x, par = 0;
+    auto rows_of_tile = [&](int tile, int* op) {
+        const int r = tile * BM + 32 * w + i;          // this lane's row
+        if (LINEAR) {
+            ri.off = r * g.a_pitch;
+            ri.ys = r < g.rows_total ? 0 : INVALID_YS;
+            ri.xs = 0;
+            if (tid < BM) op[tid] = tile * BM + tid < g.rows_total ? tile * BM + tid : -1;
+        } else {
+            dec.decode<1>(r, 0, [&](int, int n, int y, int x) { ri = make_row(g, r, n, y, x); });
+            if (tid < BM) op[tid] = out_pixel(g, tile * BM + tid);
+        }
+    };
+    auto load_frag = [&](int t) {
+        const int dy = g.dy[t], dx = g.dx[t];
+        const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[t];
+        const bool ok = ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
+        const float* p = A + (ok ? ri.off + delta : 0) + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float4 v = *reinterpret_cast<const float4*>(p + 8 * kk);
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            ra[kk] = v;
+        }
+    };
+    rows_of_tile(ltile, opix[0]);
+    load_frag(0);
+    {
+        const float* Wn0 = Wn + g.w_off[0];
+        rw0 = *reinterpret_cast<const float4*>(Wn0);
+        rw1 = *reinterpret_cast<const float4*>(Wn0 + w16);
+        rw2 = *reinterpret_cast<const float4*>(Wn0 + 2 * w16);
+        rw3 = *reinterpret_cast<const float4*>(Wn0 + 3 * w16);
+    }
+    floatx16 acc0 = {}, acc1 = {};
+    int t = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(&Ws[rb * LDA + 4 * q]) = rw0;
+        *reinterpret_cast<float4*>(&Ws[(rb + 16) * LDA + 4 * q]) = rw1;
+        *reinterpret_cast<float4*>(&Ws[(rb + 32) * LDA + 4 * q]) = rw2;
+        *reinterpret_cast<float4*>(&Ws[(rb + 48) * LDA + 4 * q]) = rw3;
+        float4 a[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) a[kk] = ra[kk];
+        __syncthreads();
+        int tn = t + 1;
+        if (tn == g.ntaps) {
+            tn = 0;
+            ltile += gridDim.x;
+            rows_of_tile(ltile, opix[par ^ 1]);
+        }
+        load_frag(tn);
+        {
+            const float* Wn1 = Wn + g.w_off[tn];
+            rw0 = *reinterpret_cast<const float4*>(Wn1);
+            rw1 = *reinterpret_cast<const float4*>(Wn1 + w16);
+            rw2 = *reinterpret_cast<const float4*>(Wn1 + 2 * w16);
+            rw3 = *reinterpret_cast<const float4*>(Wn1 + 3 * w16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float* bp0 = &Ws[i * LDA + 4 * h];
+        const float* bp1 = &Ws[(32 + i) * LDA + 4 * h];
+        float4 p4 = *reinterpret_cast<const float4*>(bp0);
+        float4 r4 = *reinterpret_cast<const float4*>(bp1);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float4 pn = p4, rn = r4;
+            if (kk < 7) {
+                pn = *reinterpret_cast<const float4*>(bp0 + 8 * kk + 8);
+                rn = *reinterpret_cast<const float4*>(bp1 + 8 * kk + 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 a4 = a[kk];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, p4.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, r4.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, p4.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, r4.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, p4.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, r4.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, p4.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
+            p4 = pn; r4 = rn;
+        }
+        if (tn == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int op = opix[par][row];
+                if (op >= 0) {
+                    const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
+                    ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
+                    ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
+                    float* o = out + (long)op * g.o_pitch + nb * 64;
+                    o[i] = apply_act<ACT>(v0);
+                    o[32 + i] = apply_act<ACT>(v1);
+                }
+            }
+            acc0 = floatx16{};
+            acc1 = floatx16{};
+            par ^= 1;
+        }
+        t = tn;
+    }
+    if (stats_part) {
+        ssum0 += __shfl_xor(ssum0, 32); ssum1 += __shfl_xor(ssum1, 32);
+        ssq0 += __shfl_xor(ssq0, 32); ssq1 += __shfl_xor(ssq1, 32);
+        __syncthreads();
+        if (h == 0) {
+            red[w * 128 + i] = ssum0; red[w * 128 + 32 + i] = ssum1;
+            red[w * 128 + 64 + i] = ssq0; red[w * 128 + 96 + i] = ssq1;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float v = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            stats_part[((long)blockIdx.y * gridDim.x + blockIdx.x) * 128 + tid] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- weight gradient
 // part[blk][t][ci][co] = sum_r T(A[src(r,t)])[ci] * G[outpix(r)][g_col + co]
 // Same software pipeline as the forward kernel: while the 64 MFMAs of a tap run, the next tap's operand rows (or
@@ -521,6 +670,14 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     if (g.rows_total == 0) return 0;
     dim3 grid(gemm_grid(g.rows_total, n_col_blocks), n_col_blocks);
     hipStream_t st = (hipStream_t)stream;
+    if (!a_scale) {          // no folded BatchNorm: operand fragments straight from global memory
+        switch (act) {
+            case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
+            case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
+            default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
+        }
+        return check_launch("conv_gemm_direct_kernel");
+    }
 #define CMVAE_LAUNCH_GEMM(ACT)                                                                                  \
     if (a_scale)                                                                                                \
         hipLaunchKernelGGL((conv_gemm_kernel<ACT, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, \
@@ -615,12 +772,11 @@ static ConvGeom linear_geom(int rows, int K, int N, int a_pitch, int o_pitch) {
 static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const float* bias, int act, int ncb,
                        float* out, hipStream_t st) {
     dim3 grid(gemm_grid(g.rows_total, ncb), ncb);
-    const float* nul = nullptr;
     float* nostats = nullptr;
     switch (act) {
-        case 0: hipLaunchKernelGGL((conv_gemm_kernel<0, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
-        case 1: hipLaunchKernelGGL((conv_gemm_kernel<1, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
-        default: hipLaunchKernelGGL((conv_gemm_kernel<2, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, nul, nul, out, nostats); break;
+        case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
+        case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
+        default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
     }
     return check_launch("conv_gemm_kernel (linear)");
 }
