@@ -96,7 +96,8 @@ def useful_flops(g, ncb):
 
 
 def pmc_traffic_conv_gemm():
-    """HBM bytes per launch of the conv launches of conv_gemm_kernel (template argument LINEAR = false), from the
+    """HBM bytes per launch of the conv launches of conv_gemm_kernel / conv_gemm_direct_kernel (last template
+    argument LINEAR = false: the launches roofline_conv_gemm times), from the
     newest committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes over this
     same workload, gfx950 correction applied).  PMC counters cannot be read from inside this process."""
     import glob
@@ -104,7 +105,8 @@ def pmc_traffic_conv_gemm():
     if not files:
         return None, None
     ks = json.load(open(files[-1]))['kernels']
-    sel = [v for k, v in ks.items() if k.startswith('conv_gemm_kernel') and k.rstrip().endswith('false>')]
+    sel = [v for k, v in ks.items()
+           if k.startswith(('conv_gemm_kernel', 'conv_gemm_direct_kernel')) and k.rstrip().endswith('false>')]
     n = sum(v['launches'] for v in sel)
     if not n:
         return None, None
@@ -139,7 +141,7 @@ def roofline_conv_gemm(step_fn):
     total_flops = sum(f for _, _, f in rec)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     traffic, src = pmc_traffic_conv_gemm()
-    return {'kernel': 'conv_gemm_kernel (conv / conv-transpose / data-gradient launches)', 'bound': 'mfma',
+    return {'kernel': 'conv_gemm_kernel + conv_gemm_direct_kernel (conv / conv-transpose / data-gradient launches)', 'bound': 'mfma',
             'achieved': round(achieved, 2),
             'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': src,
