@@ -11,8 +11,12 @@
 #define CMVAE_ABLATE_EM 0      // profiling builds only: 1 = no distance loops, 2 = no M-step MFMA
 #endif
 #include <type_traits>
+#include <utility>
 
 namespace cmvae {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ small math helpers
 // expm1 accurate to ~2e-7 relative without the cost of ocml's expm1f.
@@ -114,97 +118,137 @@ __global__ __launch_bounds__(1024) void causal_rows_kernel(const float* __restri
     }
 }
 
-// ------------------------------------------------------------------ kernel: (I + C C^T)^-1
-// One block per matrix.  C row i = causal(s_i e_i).
-constexpr int CT_LD = 68;   // C^T leading dim (float4-aligned, conflict-free float4 reads)
-constexpr int MS_LD = 65;
-
-// 1024 threads: 16 waves share the 2048 hidden units (C), a 2x2 Gram tile per thread, 4 Gauss-Jordan
-// columns per thread.
-__global__ __launch_bounds__(1024) void gram_inverse_kernel(const float* __restrict__ logvar, float s0,
-                                                            cmvae_causal c, float* __restrict__ out) {
-    __shared__ __align__(16) float CT[D * CT_LD];   // CT[j][i] = C[i][j]
-    __shared__ __align__(16) float Ms[D * MS_LD];
-    __shared__ float prow2[2 * D];                  // double-buffered pivot row / column: one barrier per step
-    __shared__ float pcol2[2 * D];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;     // w in [0,16)
-    const int m = blockIdx.x;
-    // lane = input dim i
+// ------------------------------------------------------------------ kernels: (I + C C^T)^-1
+// C row i = causal(s_i e_i).  Two launches per batch of matrices:
+//   causal_diag_kernel  grid (16, nmat): wave = one output dim j, lane = input dim i; writes C^T into out[m]
+//                       (the one-hot rows need no GEMM: 2048 fused multiply-adds + ELUs per wave).  Spreading a
+//                       matrix over 16 workgroups matters when nmat < #CUs (few-shot evaluation: 80 matrices).
+//   gram_inverse_kernel grid nmat, 4 waves: Gram matrix on the MFMA (one 32x32 tile per wave), then ONE wave inverts
+//                       it in registers (lane = row), overwriting out[m].
+__global__ __launch_bounds__(256) void causal_diag_kernel(const float* __restrict__ logvar, float s0, cmvae_causal c,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, j = 4 * blockIdx.x + (threadIdx.x >> 6);
+    const int m = blockIdx.y;
     float s = s0;
     if (logvar) s = expf(0.5f * logvar[(size_t)m * D + lane]) * s0;
+    float v;
     if (c.linear) {
         // C = S (I - A): C[i][j] = s_i (delta_ij - A[i][j])
-        for (int j = w; j < D; j += 16) {
-            float a = c.W[lane * D + j];
-            CT[j * CT_LD + lane] = s * ((lane == j ? 1.f : 0.f) - a);
-        }
+        v = s * ((lane == j ? 1.f : 0.f) - c.W[lane * D + j]);
     } else {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * w + jj;
-            float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 8
-            for (int mm = 0; mm < M1; mm += 2) {
-                const int u = 32 * j + mm;
-                const float pre0 = fmaf(s, c.W[(size_t)u * D + lane], c.b1[u]);
-                const float pre1 = fmaf(s, c.W[(size_t)(u + 1) * D + lane], c.b1[u + 1]);
-                acc0 = fmaf(elu_f(pre0), c.w2[u], acc0);
-                acc1 = fmaf(elu_f(pre1), c.w2[u + 1], acc1);
-            }
-            CT[j * CT_LD + lane] = (lane == j ? s : 0.f) - ((acc0 + acc1) + c.b2[j]);
+        float acc0 = 0.f, acc1 = 0.f;
+#if defined(CMVAE_ABLATE_GRAM) && CMVAE_ABLATE_GRAM == 2
+        for (int mm = 0; mm < 2; mm += 2) {
+#else
+#pragma unroll 16
+        for (int mm = 0; mm < M1; mm += 2) {
+#endif
+            const int u = 32 * j + mm;
+            const float pre0 = fmaf(s, c.W[(size_t)u * D + lane], c.b1[u]);
+            const float pre1 = fmaf(s, c.W[(size_t)(u + 1) * D + lane], c.b1[u + 1]);
+            acc0 = fmaf(elu_f(pre0), c.w2[u], acc0);
+            acc1 = fmaf(elu_f(pre1), c.w2[u + 1], acc1);
         }
+        v = (lane == j ? s : 0.f) - ((acc0 + acc1) + c.b2[j]);
     }
+    out[(size_t)m * D * D + j * D + lane] = v;      // C^T[j][i]
+}
+
+constexpr int MS_LD = 65;     // Gram matrix pitch in LDS: lane = row reads are conflict-free
+
+// In-place Gauss-Jordan without pivoting (SPD, eigenvalues >= 1) by one wave, lane = row r, the row in 64 registers.
+// After the pivots P = {0..p-1} the working matrix is [[A_PP^-1, X], [-X^T, S]] with S symmetric, so the pivot
+// row p is the pivot COLUMN up to a sign: every lane publishes its own column-p element (one ds_write_b32) and
+// reads the row back as 16 broadcast b128 reads -- no cross-lane register traffic, no barrier (one wave: LDS
+// operations complete in order).  The scaling of a finished pivot row is kept as a pending factor `rs`
+// (true row = rs * own): later updates of that row are then the same fused multiply-add as for every other row.
+// The column for step p+1 is updated and published first, so its LDS round trip overlaps the other 62 updates.
+template <int P>
+__device__ __forceinline__ void gauss_jordan_step(float (&own)[D], float* prow2, int lane, float& rs) {
+    const float* buf = prow2 + (P & 1) * D;
+    const float pivot = buf[P];
+    float dinv = __builtin_amdgcn_rcpf(pivot);
+    dinv = fmaf(fmaf(-pivot, dinv, 1.f), dinv, dinv);
+    const bool is_p = lane == P;
+    const float nfd = is_p ? 0.f : -own[P] * dinv;       // minus the (unscaled) multiplier of this row
+    rs = is_p ? dinv : rs;
+    if constexpr (P + 1 < D) {
+        own[P + 1] = fmaf(nfd, buf[P + 1], own[P + 1]);
+        float* nbuf = prow2 + ((P + 1) & 1) * D;
+        nbuf[lane] = lane < P + 1 ? -rs * own[P + 1] : own[P + 1];
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < D; c4 += 4) {
+        const float4 pr = *reinterpret_cast<const float4*>(buf + c4);
+        if (c4 + 0 != P && c4 + 0 != P + 1) own[c4 + 0] = fmaf(nfd, pr.x, own[c4 + 0]);
+        if (c4 + 1 != P && c4 + 1 != P + 1) own[c4 + 1] = fmaf(nfd, pr.y, own[c4 + 1]);
+        if (c4 + 2 != P && c4 + 2 != P + 1) own[c4 + 2] = fmaf(nfd, pr.z, own[c4 + 2]);
+        if (c4 + 3 != P && c4 + 3 != P + 1) own[c4 + 3] = fmaf(nfd, pr.w, own[c4 + 3]);
+    }
+    own[P] = is_p ? 1.f : nfd;
+}
+
+template <int... P>
+__device__ __forceinline__ void gauss_jordan_steps(float (&own)[D], float* prow2, int lane, float& rs,
+                                                   std::integer_sequence<int, P...>) {
+    (gauss_jordan_step<P>(own, prow2, lane, rs), ...);
+}
+
+__device__ __forceinline__ void gauss_jordan_wave(float (&own)[D], float* prow2, int lane, float& rs) {
+    rs = 1.f;
+    prow2[lane] = own[0];
+#if defined(CMVAE_ABLATE_GRAM) && CMVAE_ABLATE_GRAM == 1
+    gauss_jordan_steps(own, prow2, lane, rs, std::make_integer_sequence<int, 1>{});
+#else
+    gauss_jordan_steps(own, prow2, lane, rs, std::make_integer_sequence<int, D>{});
+#endif
+}
+
+__global__ __launch_bounds__(256) void gram_inverse_kernel(float* __restrict__ out) {
+    __shared__ __align__(16) float CT[D * D];       // CT[j][i] = C[i][j]
+    __shared__ __align__(16) float Ms[D * MS_LD];
+    __shared__ __align__(16) float prow2[2 * D];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* o = out + (size_t)blockIdx.x * D * D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        reinterpret_cast<float4*>(CT)[tid + 256 * i] = reinterpret_cast<const float4*>(o)[tid + 256 * i];
     __syncthreads();
-    // M = I + C C^T, 2x2 register tile per thread
+    // M = I + C C^T: wave w owns the 32x32 tile (ti, tk); M[i][k] = sum_j CT[j][i] CT[j][k]
     {
-        const int ti = tid >> 5, tk = tid & 31;
-        float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+        const int ti = w >> 1, tk = w & 1, l31 = lane & 31, h = lane >> 5;
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll 8
-        for (int j = 0; j < D; ++j) {
-            const float2 a = *reinterpret_cast<const float2*>(&CT[j * CT_LD + 2 * ti]);
-            const float2 b = *reinterpret_cast<const float2*>(&CT[j * CT_LD + 2 * tk]);
-            a00 = fmaf(a.x, b.x, a00); a01 = fmaf(a.x, b.y, a01);
-            a10 = fmaf(a.y, b.x, a10); a11 = fmaf(a.y, b.y, a11);
+        for (int s = 0; s < D / 2; ++s) {
+            const float av = CT[(2 * s + h) * D + 32 * ti + l31];
+            const float bv = CT[(2 * s + h) * D + 32 * tk + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
-        const int i = 2 * ti, k = 2 * tk;
-        Ms[i * MS_LD + k] = a00 + (i == k ? 1.f : 0.f);
-        Ms[i * MS_LD + k + 1] = a01;
-        Ms[(i + 1) * MS_LD + k] = a10;
-        Ms[(i + 1) * MS_LD + k + 1] = a11 + (i == k ? 1.f : 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h, col = 32 * tk + l31;
+            Ms[row * MS_LD + col] = acc[r] + (row == col ? 1.f : 0.f);
+        }
     }
     __syncthreads();
-    // in-place Gauss-Jordan (SPD, eigenvalues >= 1: no pivoting needed); thread = (row r, 4 columns)
-    const int r = tid >> 4, c0 = (tid & 15) * 4;
-    float own[4];
+    if (w != 0) return;
+    float own[D], rs;
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) own[cc] = Ms[r * MS_LD + c0 + cc];
-    for (int p = 0; p < D; ++p) {
-        float* prow = prow2 + (p & 1) * D;
-        float* pcol = pcol2 + (p & 1) * D;
-        // publish pivot row and pivot column from the registers that own them
-        if (r == p) {
+    for (int cc = 0; cc < D; ++cc) own[cc] = Ms[lane * MS_LD + cc];
+    gauss_jordan_wave(own, prow2, lane, rs);
+    // the inverse is symmetric: lane r writes its row as column r, 256 contiguous bytes per store instruction
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) prow[c0 + cc] = own[cc];
-        }
-        if ((p >> 2) == (tid & 15)) {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-                if (cc == (p & 3)) pcol[r] = own[cc];
-        }
-        __syncthreads();
-        const float dinv = 1.f / prow[p];
-        const float fd = pcol[r] * dinv;
-        if (r == p) {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) own[cc] = (c0 + cc == p) ? dinv : own[cc] * dinv;
-        } else {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) own[cc] = (c0 + cc == p) ? -fd : fmaf(-fd, prow[c0 + cc], own[cc]);
-        }
-    }
-    float* o = out + (size_t)m * D * D;
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) o[r * D + c0 + cc] = own[cc];
+    for (int cc = 0; cc < D; ++cc) o[cc * D + lane] = own[cc] * rs;
+}
+
+static int launch_gram_inverse(const float* logvar, float s0, int nmat, const cmvae_causal& c, float* out,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(causal_diag_kernel, dim3(16, nmat), dim3(256), 0, st, logvar, s0, c, out);
+    if (int e = check_launch("causal_diag_kernel")) return e;
+    hipLaunchKernelGGL(gram_inverse_kernel, dim3(nmat), dim3(256), 0, st, out);
+    return check_launch("gram_inverse_kernel");
 }
 
 // ------------------------------------------------------------------ the E/M pass
@@ -266,8 +310,6 @@ __device__ __forceinline__ float softmax_rows(float* lls, int K) {
 // The next tile's rows are fetched into registers while the current one is processed.  Per-block partials, reduced
 // by em_finalize / the reduce kernels in a fixed order: no float atomics, results reproducible.
 constexpr int TRP = 128;      // rows per tile
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // K <= 16: M-step on v_mfma_f32_16x16x4_f32 (16 components x 16 latent dims per accumulator, wave = 16-column
 // block of d), R pitch 16; K <= 32: v_mfma_f32_32x32x2_f32 (wave = (row half, d half)), R pitch 33.
@@ -850,8 +892,7 @@ extern "C" int cmvae_gram_inverse(const float* logvar, float s0, int nmat, const
     if (int e = check_causal(c)) return e;
     CMVAE_REQUIRE(out && nmat >= 0, "cmvae_gram_inverse: bad arguments");
     if (nmat == 0) return 0;
-    hipLaunchKernelGGL(gram_inverse_kernel, dim3(nmat), dim3(1024), 0, (hipStream_t)stream, logvar, s0, *c, out);
-    return check_launch("gram_inverse_kernel");
+    return launch_gram_inverse(logvar, s0, nmat, *c, out, (hipStream_t)stream);
 }
 
 extern "C" size_t cmvae_unsup_prior_workspace_bytes(int B, int N, int K) {
@@ -873,12 +914,10 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
     hipStream_t st = (hipStream_t)stream;
     const int tpb = pick_tiles_per_block(B, N), nblk = nblk_for(N, tpb);
     // initial inverse (tau0 = 1) and the loop inverse (tau = gamma1); both data independent
-    hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(1024), 0, st, nullptr, 1.0f, *c, w.minv0);
-    if (int e = check_launch("gram_inverse_kernel")) return e;
+    if (int e = launch_gram_inverse(nullptr, 1.0f, 1, *c, w.minv0, st)) return e;
     const float* minv_loop = w.minv0;
     if (gamma1 != 1.0f) {
-        hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(1024), 0, st, nullptr, gamma1, *c, w.minv);
-        if (int e = check_launch("gram_inverse_kernel")) return e;
+        if (int e = launch_gram_inverse(nullptr, gamma1, 1, *c, w.minv, st)) return e;
         minv_loop = w.minv;
     }
     FinArgs f{};
@@ -942,8 +981,7 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
     hipLaunchKernelGGL(sup_reduce_kernel, dim3(K, B), dim3(64), 0, st, w.spart_N, w.spart_S1, w.spart_S2, snblk, K,
                        w.sN, w.sS1, w.sS2);
     if (int e = check_launch("sup_reduce_kernel")) return e;
-    hipLaunchKernelGGL(gram_inverse_kernel, dim3(1), dim3(1024), 0, st, nullptr, 1.0f, *c, w.minv0);
-    if (int e = check_launch("gram_inverse_kernel")) return e;
+    if (int e = launch_gram_inverse(nullptr, 1.0f, 1, *c, w.minv0, st)) return e;
     FinArgs f{};
     f.K = K; f.fix_pi = 1; f.semi = 1; f.init = 1; f.sN = w.sN; f.sS1 = w.sS1; f.sS2 = w.sS2;
     f.minv = w.minv0; f.minv_stride = 0; f.tau_new = 1.0f; f.c = *c;
@@ -957,8 +995,7 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
     f.minv = w.minv; f.minv_stride = (size_t)D * D; f.tau_new = gamma1;
     for (int it = 0; it < iters; ++it) {
         // inverse from the incoming logvar and tau = gamma1 (omniglot/model.py:259-265)
-        hipLaunchKernelGGL(gram_inverse_kernel, dim3(B * K), dim3(1024), 0, st, logvar, gamma1, *c, w.minv);
-        if (int e = check_launch("gram_inverse_kernel")) return e;
+        if (int e = launch_gram_inverse(logvar, gamma1, B * K, *c, w.minv, st)) return e;
         if (int e = launch_pass(p, B, st)) return e;
         hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
         if (int e = check_launch("em_finalize_kernel")) return e;
