@@ -251,30 +251,32 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     train_eps = B_PER_GPU * world * args.steps / dt
 
-    # eval: GMVAE.prediction, 20-way, B=4 episodes per call (reference default), query 15
-    eval_rates = {}
+    # eval: GMVAE.prediction, 20-way, query 15; B=4 episodes per call (the reference's default batch size) and
+    # B=32 per call (same episodes, larger calls: what Trainer.eval uses with --eval-batch-size 32)
+    eval_rates, eval_rates_b32 = {}, {}
     model.eval()
-    for shot in (1, 5):
-        tr, te = WAY * shot, WAY * QUERY
-        Xtr = synth_images(B_PER_GPU, tr, device, 200 + shot)
-        Xte = synth_images(B_PER_GPU, te, device, 300 + shot)
-        ytr = torch.arange(WAY, device=device).repeat_interleave(shot)[None].repeat(B_PER_GPU, 1)
-        for _ in range(2):
-            model.prediction(Xtr, ytr, Xte)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.eval_calls):
-            y = model.prediction(Xtr, ytr, Xte)
-        barrier()
-        torch.cuda.synchronize()
-        edt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([edt], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            edt = float(t)
-        eval_rates['%dshot' % shot] = round(B_PER_GPU * world * args.eval_calls / edt, 2)
-        note('eval %d-shot done' % shot)
+    for B_eval, rates in ((B_PER_GPU, eval_rates), (32, eval_rates_b32)):
+        for shot in (1, 5):
+            tr, te = WAY * shot, WAY * QUERY
+            Xtr = synth_images(B_eval, tr, device, 200 + shot)
+            Xte = synth_images(B_eval, te, device, 300 + shot)
+            ytr = torch.arange(WAY, device=device).repeat_interleave(shot)[None].repeat(B_eval, 1)
+            for _ in range(2):
+                model.prediction(Xtr, ytr, Xte)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.eval_calls):
+                y = model.prediction(Xtr, ytr, Xte)
+            barrier()
+            torch.cuda.synchronize()
+            edt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([edt], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                edt = float(t)
+            rates['%dshot' % shot] = round(B_eval * world * args.eval_calls / edt, 2)
+            note('eval B=%d %d-shot done' % (B_eval, shot))
 
     # roofline of the dominant kernel: one extra, untimed, instrumented training step (all ranks take part:
     # the step contains the BatchNorm-statistics and gradient all-reduces)
@@ -288,7 +290,7 @@ def main():
             'config': {'workload': 'Omniglot 20-way train step: 4 episodes/GPU x sample-size 300 x 32 MC, '
                                    '10 EM iters, conv VAE + NOTEARS-MLP causal, Adam (configs[2]; the metric\'s config)',
                        'global_batch_episodes': B_PER_GPU * world, 'parallelism': 'dp%d' % world},
-            'eval_episodes_per_s': eval_rates,
+            'eval_episodes_per_s': eval_rates, 'eval_episodes_per_s_batch32': eval_rates_b32,
             'final_losses': {'rec': losses[0], 'kl': losses[1], 'h_aug': losses[2]},
         }
         out['roofline'] = roof

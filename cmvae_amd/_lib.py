@@ -62,6 +62,8 @@ SIGNATURES = {
     'cmvae_colsum_reduce': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_bn_finalize': (c_int, [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_bn_eval_fold': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
     'cmvae_rowpass_grid': (c_int, [c_int64]),
     'cmvae_bn_relu_bwd_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                          c_void_p, c_void_p]),

@@ -58,6 +58,20 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
     }
 }
 
+// eval mode: the fold from the running statistics (nn.BatchNorm2d.eval())
+__global__ void bn_eval_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                    float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                    float* __restrict__ invstd_o) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const float invstd = rsqrtf(running_var[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - running_mean[c] * sc;
+    invstd_o[c] = invstd;
+}
+
 // ------------------------------------------------------------------ BN + ReLU backward
 // dybn = d_a * (y*scale+shift > 0);  part[blk] = {sum dybn[64], sum dybn*xhat[64]}
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __restrict__ d_a,
@@ -478,6 +492,17 @@ extern "C" int cmvae_bn_finalize(const float* sums, double count, const float* g
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, (float)count, gamma, beta,
                        eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
     return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int cmvae_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, float* invstd,
+                                  void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && invstd,
+                  "cmvae_bn_eval_fold: NULL tensor");
+    hipLaunchKernelGGL(bn_eval_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, scale, shift, invstd);
+    return check_launch("bn_eval_fold_kernel");
 }
 
 extern "C" int cmvae_rowpass_grid(int64_t rows) {

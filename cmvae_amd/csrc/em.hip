@@ -556,12 +556,25 @@ __global__ __launch_bounds__(1024) void em_finalize_kernel(FinArgs a) {
     const int k = blockIdx.x, b = blockIdx.y, K = a.K;
     float S1 = 0.f, S2 = 0.f, Nk = 0.f, pi_k = 1.f / K;
     float uN = 0.f;
+    // operands that do not depend on the reduction are requested first: their latency hides behind it
+    const float* Mi = a.minv + (a.minv_stride ? ((size_t)b * K + k) * a.minv_stride : 0);
+    float mi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mi[i] = Mi[(4 * w + i) * D + lane];
+    float sup1 = 0.f, sup2 = 0.f, supN = 0.f;
+    if (a.semi) {
+        supN = a.sN[b * K + k];
+        if (tid < D) {
+            sup1 = a.sS1[((size_t)b * K + k) * D + tid];
+            if (!a.init) sup2 = a.sS2[((size_t)b * K + k) * D + tid];
+        }
+    }
 
     if (a.init && !a.semi) {
         // mean0 = z[idx] (then shrunk below)
         if (tid < D) ms[tid] = a.z[((size_t)b * a.N + a.init_idx[b * K + k]) * D + tid];
     } else if (a.init && a.semi) {
-        if (tid < D) ms[tid] = a.sS1[((size_t)b * K + k) * D + tid] / a.sN[b * K + k];
+        if (tid < D) ms[tid] = sup1 / supN;
     } else {
         // ---- N_k' for every component (needed for pi), fixed-order reduction
         {
@@ -603,17 +616,16 @@ __global__ __launch_bounds__(1024) void em_finalize_kernel(FinArgs a) {
             if (!a.fix_pi) pi_k = Nk / ntot;
             if (tid < D) ms[tid] = S1 / Nk;
         } else {
-            Nk = a.sN[b * K + k] + uN;     // joint denominator
-            if (tid < D) ms[tid] = (a.sS1[((size_t)b * K + k) * D + tid] + S1) / Nk;
+            Nk = supN + uN;                // joint denominator
+            if (tid < D) ms[tid] = (sup1 + S1) / Nk;
         }
     }
     __syncthreads();
     // ---- shrink: mean = m (row vector) @ Minv
     {
-        const float* Mi = a.minv + (a.minv_stride ? ((size_t)b * K + k) * a.minv_stride : 0);
         float acc = 0.f;
 #pragma unroll
-        for (int i = 4 * w; i < 4 * w + 4; ++i) acc = fmaf(ms[i], Mi[i * D + lane], acc);
+        for (int i = 0; i < 4; ++i) acc = fmaf(ms[4 * w + i], mi[i], acc);
         __syncthreads();             // everyone is done reading red/red2 as partial sums
         red[w * D + lane] = acc;
     }
@@ -627,11 +639,8 @@ __global__ __launch_bounds__(1024) void em_finalize_kernel(FinArgs a) {
         if (a.semi) {
             float lv = 0.f;
             if (!a.init) {
-                const float sS1 = a.sS1[((size_t)b * K + k) * D + tid];
-                const float sS2 = a.sS2[((size_t)b * K + k) * D + tid];
-                const float sN = a.sN[b * K + k];
                 const float m2 = mean * mean;
-                const float svar = sS2 - 2.f * (mean * sS1) + sN * m2;
+                const float svar = sup2 - 2.f * (mean * sup1) + supN * m2;
                 const float uvar = S2 - 2.f * (mean * S1) + uN * m2;
                 lv = logf((svar + uvar) / Nk);
             }

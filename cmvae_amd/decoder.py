@@ -44,8 +44,10 @@ def bn_finalize(sums, count, bn, training_update=True):
 
 
 def bn_eval_fold(bn):
-    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
-    return scale, bn.bias.detach() - bn.running_mean * scale, bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+    scale, shift, invstd = (torch.empty(64, device=bn.weight.device) for _ in range(3))
+    check(lib.cmvae_bn_eval_fold(_p(bn.weight.detach()), _p(bn.bias.detach()), _p(bn.running_mean), _p(bn.running_var),
+                                 bn.eps, _p(scale), _p(shift), _p(invstd), _stream()), 'cmvae_bn_eval_fold')
+    return scale, shift, bn.running_mean, invstd
 
 
 def _global_sums(sums):

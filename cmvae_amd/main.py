@@ -34,6 +34,9 @@ def build_parser(variant):
     p.add_argument('--train-iters', type=int, default=d['iters'])
     p.add_argument('--freq-iters', type=int, default=1000)
     p.add_argument('--eval-episodes', type=int, default=1000)
+    p.add_argument('--eval-batch-size', type=int, default=None,
+                   help='episodes per prediction call during evaluation (default: --batch-size, as the reference; '
+                        '32 doubles the evaluation throughput on one MI355X)')
     if variant != 'omniglot':
         p.add_argument('--shot', type=int, default=1)
         p.add_argument('--seed', type=int, default=15)

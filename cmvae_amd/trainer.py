@@ -160,18 +160,21 @@ class Trainer(object):
     # ------------------------------------------------------------------ evaluation
     def eval(self, shot, test=False):
         """Mean accuracy and 95 % interval over `eval_episodes` test episodes.  Episodes are drawn from the single
-        host numpy stream in batches of `batch_size` and dealt contiguously to the ranks; only the per-episode
+        host numpy stream in batches of `eval_batch_size` (default `batch_size`, as the reference) and dealt contiguously to the ranks; only the per-episode
         accuracies are gathered."""
         a = self.args
         self.model.eval()
         accs = []
-        sl = cdist.shard_slice(a.batch_size, self.rank, self.world)
-        for _ in range(max(1, a.eval_episodes // a.batch_size)):
+        eb = getattr(a, 'eval_batch_size', None) or a.batch_size       # episodes per prediction call, all ranks
+        if eb % self.world:
+            raise ValueError('eval batch size %d is not divisible by %d ranks' % (eb, self.world))
+        sl = cdist.shard_slice(eb, self.rank, self.world)
+        for _ in range(max(1, -(-a.eval_episodes // eb))):
             X_tr, y_tr, X_te, y_te = self.data.generate_test_episode(way=a.way, shot=shot, query=a.query,
-                                                                     n_episodes=a.batch_size, test=test)
+                                                                     n_episodes=eb, test=test)
             y_pred = self.model.prediction(X_tr[sl].contiguous(), y_tr[sl].contiguous(), X_te[sl].contiguous())
             accs.append(torch.eq(y_pred, y_te[sl]).float().mean(-1))
         acc = torch.cat(accs)                                          # one device->host copy per eval
-        acc = cdist.gather_episode_values(acc, self.local_batch)
+        acc = cdist.gather_episode_values(acc, eb // self.world)
         acc = acc.cpu().numpy().astype(np.float64)[:a.eval_episodes]
         return float(np.mean(acc)), float(1.96 * np.std(acc) / np.sqrt(a.eval_episodes))

@@ -216,6 +216,11 @@ int cmvae_colsum_reduce(const float* part, int nblk, int L, float* out, void* st
 int cmvae_bn_finalize(const float* sums, double count, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var,
                       float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* model.eval(): the same fold from the running statistics (nn.BatchNorm2d in eval mode, used by
+ * GMVAE.prediction, omniglot/model.py:520-585): scale = gamma*rsqrt(running_var+eps),
+ * shift = beta - running_mean*scale, invstd.                                                   */
+int cmvae_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* scale, float* shift, float* invstd, void* stream);
 /* backward of relu(bn(y)): dybn = d_a*(bn(y)>0) (masked != 0: d_a is already masked);
  * part [cmvae_rowpass_grid(rows)][128] = {sum dybn, sum dybn*xhat}; then
  * dy = scale*(dybn - c1 - xhat*c2) with c1, c2 from cmvae_bn_bwd_finalize.                     */

@@ -62,6 +62,16 @@ def test_feature_trainers_run(tmp_path, variant):
     assert all(np.isfinite(m) for m, _ in out.values())
 
 
+def test_eval_batch_size_is_independent_of_train_batch_size(tmp_path):
+    """--eval-batch-size: larger prediction calls, episode count rounded up and trimmed (7 episodes in calls of 3)."""
+    from cmvae_amd.trainer import Trainer
+    d = _make(tmp_path, 'omniglot')
+    np.random.seed(10086); torch.manual_seed(10086)
+    tr = Trainer(_args(d, str(tmp_path / 'run'), eval_batch_size=3, eval_episodes=7), 'omniglot')
+    mean, conf = tr.eval(1, test=True)
+    assert 0.0 <= mean <= 1.0 and np.isfinite(conf)
+
+
 def test_cli_entry_point_in_a_fresh_process(tmp_path):
     """`python omniglot/main.py ...` (the reference's command line): imports the package before torch, which must
     still bind the HIP library to PyTorch's runtime (cmvae_amd/_lib.py)."""
