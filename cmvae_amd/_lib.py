@@ -79,6 +79,8 @@ SIGNATURES = {
                                   c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     'cmvae_dec_out_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_enc_conv1_pool_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                         c_void_p]),
     'cmvae_enc_conv1_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'cmvae_enc_conv1_wgrad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_pool_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -70,6 +70,68 @@ __global__ __launch_bounds__(256) void enc_conv1_fwd_kernel(const float* __restr
     }
 }
 
+// Evaluation mode (BatchNorm from the running statistics, nothing kept for a backward pass): conv 1->64, the
+// BatchNorm fold, ReLU and MaxPool2d(2, ceil_mode) in one pass.  The 64-channel pre-pooling activation (200 KB per
+// 28x28 image, the largest tensor of GMVAE.prediction) is never written: HBM traffic is the image plus the pooled
+// output.  x [n,H,W]; out [n*Ho*Wo, 64] = max over the (clipped) 2x2 window of relu(scale*conv+shift).
+__global__ __launch_bounds__(256) void enc_conv1_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int H, int W, int nimg,
+                                                             float* __restrict__ out) {
+    __shared__ float xs[36 * 36];          // zero-padded image, one extra row/column for the odd-size window
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
+    float wr[4][9], br[4], sc[4], sh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        br[c] = b[4 * q + c]; sc[c] = scale[4 * q + c]; sh[c] = shift[4 * q + c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(4 * q + c) * 9 + t];
+    }
+    const int hw = H * W, PW = W + 4, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    for (int e = threadIdx.x; e < (H + 4) * PW; e += 256) xs[e] = 0.f;
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+        __syncthreads();
+        const float* xi = x + (long)img * hw;
+        for (int e = threadIdx.x; e < hw; e += 256) {
+            const int py = e / W;
+            xs[(py + 1) * PW + (e - py * W) + 1] = xi[e];
+        }
+        __syncthreads();
+        float* oi = out + (long)img * Ho * Wo * EC;
+        for (int op = rb; op < Ho * Wo; op += 16) {
+            const int oy = op / Wo, ox = op - oy * Wo;
+            const float* xp = &xs[(2 * oy) * PW + 2 * ox];       // 4x4 input patch of the 2x2 window
+            float patch[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) patch[i][j] = xp[i * PW + j];
+            float best[4] = {0.f, 0.f, 0.f, 0.f};                 // ReLU floor
+#pragma unroll
+            for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+                for (int wx = 0; wx < 2; ++wx) {
+                    const bool inside = (2 * oy + wy < H) && (2 * ox + wx < W);
+                    float acc[4] = {br[0], br[1], br[2], br[3]};
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[c] = fmaf(patch[wy + ky][wx + kx], wr[c][ky * 3 + kx], acc[c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = fmaf(acc[c], sc[c], sh[c]);
+                        best[c] = inside ? fmaxf(best[c], v) : best[c];
+                    }
+                }
+            reinterpret_cast<float4*>(oi + op * EC)[q] = make_float4(best[0], best[1], best[2], best[3]);
+        }
+    }
+}
+
 // part[blk][640] = { dW[64][9], db[64] },  dW[c][t] = sum_r dy[r][c] * x[src(r,t)]
 __global__ __launch_bounds__(256) void enc_conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               int H, int W, long rows, float* __restrict__ part) {
@@ -238,6 +300,17 @@ extern "C" int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* 
     hipLaunchKernelGGL(enc_conv1_fwd_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, w, b, H, W, n,
                        y, stats_part);
     return check_launch("enc_conv1_fwd_kernel");
+}
+
+extern "C" int cmvae_enc_conv1_pool_fwd(const float* x, const float* w, const float* b, const float* scale,
+                                        const float* shift, int n, int H, int W, float* out, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(x && w && b && scale && shift && out && n >= 1, "cmvae_enc_conv1_pool_fwd: bad arguments");
+    CMVAE_REQUIRE(H >= 1 && W >= 1 && H <= 32 && W <= 32, "cmvae_enc_conv1_pool_fwd: image %dx%d exceeds 32x32", H, W);
+    const int grid = n < 2048 ? n : 2048;
+    hipLaunchKernelGGL(enc_conv1_pool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, b, scale, shift, H, W,
+                       n, out);
+    return check_launch("enc_conv1_pool_kernel");
 }
 
 extern "C" int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, float* part, void* stream) {

@@ -29,6 +29,15 @@ class _Encoder(torch.autograd.Function):
         a = None
         for li, H in enumerate(_SIZES):
             rows = n * H * H
+            Ho = (H + 1) // 2
+            if li == 0 and not training:
+                # evaluation: conv1 + BatchNorm(running statistics) + ReLU + pooling in one pass, y1 never exists
+                fold = bn_eval_fold(bns[0])
+                a = torch.empty(n * Ho * Ho, 64, device=dev)
+                check(lib.cmvae_enc_conv1_pool_fwd(_p(x), _p(w1.detach().reshape(64, 9)), _p(b1.detach()), _p(fold[0]),
+                                                   _p(fold[1]), n, H, H, _p(a), _stream()), 'cmvae_enc_conv1_pool_fwd')
+                ys.append(None); folds.append(fold); pooled.append(a)
+                continue
             y = torch.empty(rows, 64, device=dev)
             part = None
             if li == 0:
@@ -43,7 +52,6 @@ class _Encoder(torch.autograd.Function):
                 fold = bn_finalize(_global_sums(colsum(part)), rows * world, bns[li])
             else:
                 fold = bn_eval_fold(bns[li])
-            Ho = (H + 1) // 2
             a = torch.empty(n * Ho * Ho, 64, device=dev)
             check(lib.cmvae_pool_fwd(_p(y), _p(fold[0]), _p(fold[1]), n, H, H, _p(a), _stream()), 'cmvae_pool_fwd')
             ys.append(y); folds.append(fold); pooled.append(a)

@@ -267,6 +267,11 @@ int cmvae_dec_out_bwd_apply(const float* y3, const float* scale, const float* sh
 int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* b, int n, int H, int W,
                         float* y, float* stats_part, void* stream);
 int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, float* part, void* stream);
+/* model.eval() (GMVAE.prediction, omniglot/model.py:520-531 -> module.py:14-17): Conv2d(1,64,3,1,1), BatchNorm from
+ * the running statistics (scale/shift of cmvae_bn_eval_fold), ReLU and MaxPool2d(2, ceil_mode=True) in one pass:
+ * x [n,H,W] -> out [n,ceil(H/2),ceil(W/2),64]; the pre-pooling activation is never written.  H, W <= 32.      */
+int cmvae_enc_conv1_pool_fwd(const float* x, const float* w, const float* b, const float* scale, const float* shift,
+                             int n, int H, int W, float* out, void* stream);
 int cmvae_pool_fwd(const float* y, const float* scale, const float* shift, int n, int H, int W,
                    float* out, void* stream);
 int cmvae_pool_bwd(const float* d_pool, const float* y, const float* scale, const float* shift,

@@ -128,3 +128,31 @@ def test_linear_fwd_dgrad_wgrad(device, rows, K, N, act):
                         db=db[nb * 64:], g_pitch=N, g_col=nb * 64)
     assert rel_err(dW, w.grad) < TOL
     assert rel_err(db, b.grad) < TOL
+
+
+@pytest.mark.parametrize('n,H,W', [(5, 28, 28), (3, 7, 7), (2, 13, 9), (300, 28, 28)])
+def test_enc_conv1_pool_eval_kernel(device, n, H, W):
+    """Fused Conv2d(1,64,3,1,1) + BatchNorm(eval) + ReLU + MaxPool2d(2, ceil_mode=True) (omniglot/module.py:14-17)
+    against the same four torch ops in fp32; odd sizes exercise the clipped pooling window."""
+    from cmvae_amd._lib import lib, check
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(n, 1, H, W, generator=g) < 0.3).float()
+    w = torch.randn(64, 1, 3, 3, generator=g) * 0.4
+    b = torch.randn(64, generator=g) * 0.1
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    rm, rv = torch.randn(64, generator=g) * 0.3, torch.rand(64, generator=g) + 0.3
+    ref = F.max_pool2d(F.relu(F.batch_norm(F.conv2d(x, w, b, padding=1), rm, rv, gamma, beta, False, 0.1, 1e-5)), 2,
+                       ceil_mode=True)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, 64)                      # channels-last rows
+    d = lambda t: t.to(device).contiguous()                            # noqa: E731
+    scale, shift, invstd = (torch.empty(64, device=device) for _ in range(3))
+    st = torch.cuda.current_stream().cuda_stream
+    gm, bt, rmd, rvd = d(gamma), d(beta), d(rm), d(rv)
+    check(lib.cmvae_bn_eval_fold(gm.data_ptr(), bt.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), 1e-5, scale.data_ptr(),
+                                 shift.data_ptr(), invstd.data_ptr(), st), 'cmvae_bn_eval_fold')
+    assert rel_err(invstd, torch.rsqrt(rv + 1e-5)) < 1e-6
+    xd, wd, bd = d(x.reshape(n, H * W)), d(w.reshape(64, 9)), d(b)
+    out = torch.empty(ref.shape[0], 64, device=device)
+    check(lib.cmvae_enc_conv1_pool_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                       n, H, W, out.data_ptr(), st), 'cmvae_enc_conv1_pool_fwd')
+    assert rel_err(out, ref) < 1e-5
