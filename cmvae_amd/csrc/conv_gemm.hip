@@ -569,12 +569,13 @@ struct WgradOut {
     long tap_off[32];
     long s_ci, s_co, y_stride;
 };
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nblk, int NT,
-                                                           WgradOut o, float* __restrict__ dW,
-                                                           const float* __restrict__ db_part,
-                                                           float* __restrict__ db, int accumulate_db) {
-    // 64 consecutive elements x 4 groups of partial blocks per workgroup; fixed summation order
-    __shared__ float red[4 * 64];
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int nblk, int NT,
+                                                            WgradOut o, float* __restrict__ dW,
+                                                            const float* __restrict__ db_part,
+                                                            float* __restrict__ db, int accumulate_db) {
+    // 64 consecutive elements x 16 groups of partial blocks per workgroup (enough loads in flight to cover the
+    // latency of up to 512 partials per element); fixed summation order
+    __shared__ float red[16 * 64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + c;
     const long slot = (long)(blockIdx.z * gridDim.y + blockIdx.y) * nblk;
@@ -584,19 +585,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     float s0 = 0.f, s1 = 0.f;
     if (!is_db) {
         int b = g;
-        for (; b + 4 < nblk; b += 8) {
+        for (; b + 112 < nblk; b += 128) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = part[(long)(b + 16 * i) * NT * 4096 + e];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) { s0 += v[i]; s1 += v[i + 1]; }
+        }
+        for (; b + 16 < nblk; b += 32) {
             s0 += part[(long)b * NT * 4096 + e];
-            s1 += part[(long)(b + 4) * NT * 4096 + e];
+            s1 += part[(long)(b + 16) * NT * 4096 + e];
         }
         if (b < nblk) s0 += part[(long)b * NT * 4096 + e];
     } else {
         db_part += slot * 64;
-        for (int b = g; b < nblk; b += 4) s0 += db_part[(long)b * 64 + c];
+        for (int b = g; b < nblk; b += 16) s0 += db_part[(long)b * 64 + c];
     }
     red[g * 64 + c] = s0 + s1;
     __syncthreads();
     if (g != 0) return;
-    const float s = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r * 64 + c];
     if (!is_db) {
         const int t = e >> 12, ci = (e >> 6) & 63, co = e & 63;
         dW[blockIdx.y * o.y_stride + o.tap_off[NT * blockIdx.z + t] + ci * o.s_ci + co * o.s_co] = s;
@@ -730,7 +740,7 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
         }
         if (int e = check_launch("conv_wgrad_kernel")) return e;
         for (int t = 0; t < nt * nz; ++t) o.tap_off[t] = tap_off_host[t0 + t];
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nt * 64 + 1, ny, nz), dim3(256), 0, st, part, nblk, nt, o, dW,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nt * 64 + 1, ny, nz), dim3(1024), 0, st, part, nblk, nt, o, dW,
                            dbp, dbp ? db : nullptr, accumulate_db);
         if (int e = check_launch("wgrad_reduce_kernel")) return e;
     }

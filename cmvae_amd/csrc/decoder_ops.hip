@@ -18,6 +18,14 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
     float s0 = 0.f, s1 = 0.f;
     if (e < L) {
         int b = g;
+        // eight loads in flight per thread: the kernel is pure latency (two workgroups for the 128 BatchNorm sums)
+        for (; b + 112 < nblk; b += 128) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = part[(long)(b + 16 * i) * L + e];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) { s0 += v[i]; s1 += v[i + 1]; }
+        }
         for (; b + 16 < nblk; b += 32) {
             s0 += part[(long)b * L + e];
             s1 += part[(long)(b + 16) * L + e];
