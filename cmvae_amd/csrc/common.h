@@ -25,6 +25,20 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
+// Workgroups of `kernel` the device keeps resident at once (CUs x occupancy): the grid of a persistent kernel
+// that loops over its work items, so that no second, partly filled round of workgroups trails the first.
+inline int resident_blocks(const void* kernel, int block_threads, int fallback) {
+    int dev = 0, cus = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block_threads, 0) != hipSuccess || cus < 1 ||
+        occ < 1) {
+        (void)hipGetLastError();
+        return fallback;
+    }
+    return cus * occ;
+}
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
