@@ -75,8 +75,11 @@ def roofline_em_pass(device):
         ms = event_time_ms(lambda: ops.em_pass(z, mu, logw, ws), 50, stream)
         alg_bytes = B * (N * 64 * 4 + K * (2 * 64 + 2) * 4)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
+        name = 'em_pass_kernel<%d, false, false>' % ((K + 1) // 2)     # the instantiation this shape launches
+        traffic, src = pmc_traffic(lambda k: k == name)
         out.append({'kernel': 'em_pass_kernel', 'shape': tag, 'bound': 'hbm', 'achieved': round(achieved, 1),
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'traffic_source': src,
                     'launch_us': round(ms * 1e3, 2), 'algorithmic_bytes': alg_bytes,
                     'note': 'back-to-back launches from Python: includes host launch gaps'})
         del z
@@ -95,22 +98,26 @@ def useful_flops(g, ncb):
     return 2.0 * 64 * 64 * taps * n_img * ncb
 
 
-def pmc_traffic_conv_gemm():
-    """HBM bytes per launch of the conv launches of conv_gemm_kernel / conv_gemm_direct_kernel (last template
-    argument LINEAR = false: the launches roofline_conv_gemm times), from the
-    newest committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes over this
-    same workload, gfx950 correction applied).  PMC counters cannot be read from inside this process."""
+def pmc_traffic(select):
+    """HBM bytes per launch, launch-weighted over the kernels whose rocprof name satisfies `select`, from the newest
+    committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes over this same
+    workload, gfx950 correction applied).  PMC counters cannot be read from inside this process."""
     import glob
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_traffic.json')))
     if not files:
         return None, None
     ks = json.load(open(files[-1]))['kernels']
-    sel = [v for k, v in ks.items()
-           if k.startswith(('conv_gemm_kernel', 'conv_gemm_direct_kernel')) and k.rstrip().endswith('false>')]
+    sel = [v for k, v in ks.items() if select(k.rstrip())]
     n = sum(v['launches'] for v in sel)
     if not n:
         return None, None
     return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / n, os.path.basename(files[-1])
+
+
+def pmc_traffic_conv_gemm():
+    """The conv launches of conv_gemm_kernel / conv_gemm_direct_kernel (last template argument LINEAR = false:
+    the launches roofline_conv_gemm times)."""
+    return pmc_traffic(lambda k: k.startswith(('conv_gemm_kernel', 'conv_gemm_direct_kernel')) and k.endswith('false>'))
 
 
 def roofline_conv_gemm(step_fn):
