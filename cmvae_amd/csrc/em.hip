@@ -351,13 +351,15 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
     }
 
     const int tile0 = blk * a.tiles_per_block;
+    // The next tile is fetched one iteration ahead and used raw: rows beyond N are zeroed when the tile is written
+    // to LDS, not when it is loaded (a select right after the load would wait for it and expose the whole HBM
+    // latency).
     float4 pre[8];
     auto fetch = [&](int row0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int r = row0 + lr + 16 * e;
             pre[e] = reinterpret_cast<const float4*>(zb + (size_t)(r < N ? r : 0) * D)[q];
-            if (r >= N) pre[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (tile0 * TRP < N) fetch(tile0 * TRP);
@@ -366,17 +368,26 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
         if (row0 >= N) break;          // uniform across the block
         __syncthreads();               // previous tile fully consumed (also covers mus / lws / Rs stores)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<float4*>(&zs[(lr + 16 * e) * ZS_LD + 4 * q]) = pre[e];
+        for (int e = 0; e < 8; ++e) {
+            float4 v = pre[e];
+            if (row0 + lr + 16 * e >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&zs[(lr + 16 * e) * ZS_LD + 4 * q]) = v;
+        }
         __syncthreads();
-        if (t + 1 < a.tiles_per_block && row0 + TRP < N) fetch(row0 + TRP);
         const bool valid = row0 + erow < N;
+        // per-row operands from global memory are requested before the prefetch (see above)
+        int64_t lab = -1;
+        float gv = 1.f;
+        if (a.labels && valid) lab = a.labels[(size_t)b * N + row0 + erow];
+        if (DZ && a.g && valid) gv = a.g[(size_t)b * N + row0 + erow];
+        if (t + 1 < a.tiles_per_block && row0 + TRP < N) fetch(row0 + TRP);
         float r[KH];
         if (a.labels) {
-            const int64_t lab = valid ? a.labels[(size_t)b * N + row0 + erow] : -1;
 #pragma unroll
             for (int j = 0; j < KH; ++j) r[j] = (lab == half + 2 * j) ? 1.f : 0.f;
         } else {
-            // squared distances, the row taken in two halves of 32 dims to keep it in 32 registers
+            // squared distances, the row taken in two halves of 32 dims to keep it in 32 registers (packed
+            // v_pk_fma_f32 math was measured: no faster at K = 5, 25 % slower at K = 16)
 #pragma unroll
             for (int j = 0; j < KH; ++j) r[j] = 0.f;
 #if !(CMVAE_ABLATE_EM & 1)
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
             sum += __shfl_xor(sum, 1);
             const float lse = mx + logf(sum);
             if (a.lse && half == 0 && valid) a.lse[(size_t)b * N + row0 + erow] = lse;
-            const float gs = !valid ? 0.f : (a.g ? a.g[(size_t)b * N + row0 + erow] : 1.f);
+            const float gs = valid ? gv : 0.f;
 #pragma unroll
             for (int j = 0; j < KH; ++j) r[j] = expf(r[j] - lse) * gs;
         }
@@ -786,13 +797,15 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------ host side
+// Split every episode's tiles over as many workgroups as stay resident at once (3 per CU on 256 CUs; the em_pass
+// instantiations for K > 16 and the dz variant hold 2 per CU, their second round is a short one): a single
+// workgroup per CU would serialise its own load -> E-step -> M-step phases with nothing to overlap them.
 static int pick_tiles_per_block(int B, int N) {
     const int tiles_ep = (N + TRP - 1) / TRP;
-    const long total = (long)tiles_ep * B;
-    int tpb = (int)(total / 256);
-    if (tpb > tiles_ep) tpb = tiles_ep;
-    if (tpb < 1) tpb = 1;
-    return tpb;
+    int nblk = (768 + B - 1) / B;                       // workgroups per episode
+    if (nblk > tiles_ep) nblk = tiles_ep;
+    if (nblk < 1) nblk = 1;
+    return (tiles_ep + nblk - 1) / nblk;
 }
 static int nblk_for(int N, int tpb) {
     const int tiles_ep = (N + TRP - 1) / TRP;
