@@ -2,24 +2,20 @@
 //   O[b,i,h,:] = Q[b,i,h,:] + sum_j softmax_j(scale * Q[b,i,h,:].K[b,j,h,:]) V[b,j,h,:]
 // Q, K, V, O are [B, S, H*64] row-major (the head is a 64-column slice of the row).  One workgroup owns 16
 // query rows (forward, dQ) or 16 key rows (dK/dV) of one (episode, head); the S x 16 score strip lives in LDS.
-// Sets are small (S = 5 ... a few hundred), so these are latency-bound VALU kernels.
+// Both contractions of every kernel (scores = tile . M^T into the strip, output = strip . M) run on
+// v_mfma_f32_16x16x4_f32; softmax and the dS algebra stay on the VALU, 16 lanes per row.
 #include "common.h"
 
 namespace cmvae {
 
-constexpr int AT = 16;            // rows per workgroup
-constexpr int ATT_MAX_S = 1024;   // 2 strips * 16 * 1024 * 4 B = 128 KB of LDS in the backward kernels
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float dot64(const float4* __restrict__ a_lds, const float4 (&b)[16]) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-        const float4 a0 = a_lds[c], a1 = a_lds[c + 1];
-        s0 = fmaf(a0.x, b[c].x, fmaf(a0.y, b[c].y, fmaf(a0.z, b[c].z, fmaf(a0.w, b[c].w, s0))));
-        s1 = fmaf(a1.x, b[c + 1].x, fmaf(a1.y, b[c + 1].y, fmaf(a1.z, b[c + 1].z, fmaf(a1.w, b[c + 1].w, s1))));
-    }
-    return s0 + s1;
-}
+constexpr int AT = 16;            // rows per workgroup
+constexpr int ATT_MAX_S = 1024;   // 2 strips * 16 * 1028 * 4 B + 2 tiles = 137 KB of LDS in the backward kernels
+
+// pitch of a 16 x S strip in LDS: S rounded up to whole 16-column MFMA tiles, + 4 so that the 16 rows of an
+// A-fragment read fall into different banks
+__host__ __device__ inline int strip_pitch(int S) { return ((S + 15) / 16) * 16 + 4; }
 
 __device__ __forceinline__ float group16_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
@@ -31,9 +27,98 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ void load_row16(const float* __restrict__ p, float4 (&r)[16]) {
+// ---------------------------------------------------------------------------- the two MFMA building blocks
+// (v_mfma_f32_16x16x4_f32: A[m = lane&15][k = lane>>4], B[k = lane>>4][n = lane&15], C[row = 4*(lane>>4) + reg]
+//  [col = lane&15]; the contraction index may be permuted freely as long as A and B agree, so lane group g takes
+//  channels 16g .. 16g+15: its B operand is 64 contiguous bytes of a global row.)
+//
+// strip_mfma: T1[m][j] = tile1[m][:] . M1[j][:]  (and T2 from tile2, M2) for all j < S, 16 columns per wave step;
+// tile* are [16][64] in LDS, M* global matrices with row stride C.  emit(m, j, t1, t2) is called for every element
+// of the 16-column tiles (j may be >= S in the last tile: the caller stores zeros there).
+template <bool DUAL, typename F>
+__device__ __forceinline__ void strip_mfma(const float* tile1, const float* __restrict__ M1, const float* tile2,
+                                           const float* __restrict__ M2, int S, int C, F&& emit) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    float a1[16], a2[DUAL ? 16 : 1];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) r[c] = reinterpret_cast<const float4*>(p)[c];
+    for (int c = 0; c < 4; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(tile1 + n * 64 + 16 * g + 4 * c);
+        a1[4 * c] = v.x; a1[4 * c + 1] = v.y; a1[4 * c + 2] = v.z; a1[4 * c + 3] = v.w;
+        if (DUAL) {
+            const float4 u = *reinterpret_cast<const float4*>(tile2 + n * 64 + 16 * g + 4 * c);
+            a2[4 * c] = u.x; a2[4 * c + 1] = u.y; a2[4 * c + 2] = u.z; a2[4 * c + 3] = u.w;
+        }
+    }
+    const int ntile = (S + 15) / 16;
+    for (int jt = w; jt < ntile; jt += 4) {
+        const int j = 16 * jt + n, jc = j < S ? j : S - 1;
+        float4 b1[4], b2[DUAL ? 4 : 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            b1[c] = *reinterpret_cast<const float4*>(M1 + (long)jc * C + 16 * g + 4 * c);
+            if (DUAL) b2[c] = *reinterpret_cast<const float4*>(M2 + (long)jc * C + 16 * g + 4 * c);
+        }
+        floatx4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, r0 = p0, r1 = p0;     // two chains per product
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * c], b1[c].x, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * c + 1], b1[c].y, p1, 0, 0, 0);
+            if (DUAL) {
+                r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * c], b2[c].x, r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * c + 1], b2[c].y, r1, 0, 0, 0);
+            }
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * c + 2], b1[c].z, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * c + 3], b1[c].w, p1, 0, 0, 0);
+            if (DUAL) {
+                r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * c + 2], b2[c].z, r0, 0, 0, 0);
+                r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * c + 3], b2[c].w, r1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) emit(4 * g + reg, j, p0[reg] + p1[reg], DUAL ? r0[reg] + r1[reg] : 0.f);
+    }
+}
+
+// out_mfma: O1[m][c] = sum_{j < S} strip1[m][j] * M1[j][c]  (and O2 from strip2, M2); wave w owns channels
+// 16w .. 16w+15.  Strip columns S .. 16*ceil(S/16)-1 must hold zeros.  Returns the accumulators:
+// element reg <-> (row 4*(lane>>4) + reg, channel 16w + (lane&15)).
+template <bool DUAL>
+__device__ __forceinline__ void out_mfma(const float* strip1, const float* __restrict__ M1, const float* strip2,
+                                         const float* __restrict__ M2, int S, int C, floatx4& o1, floatx4& o2) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int SPP = strip_pitch(S), ntile = (S + 15) / 16;
+    floatx4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, r0 = p0, r1 = p0;
+    const float* s1 = strip1 + n * SPP + g;
+    const float* s2 = DUAL ? strip2 + n * SPP + g : nullptr;
+    const float* m1 = M1 + 16 * w + n;
+    const float* m2 = DUAL ? M2 + 16 * w + n : nullptr;
+    for (int jt = 0; jt < ntile; ++jt) {
+        float a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                     // four k-steps of four rows: all operands requested first
+            const int j = 16 * jt + 4 * q + g;
+            const long o = (long)(j < S ? j : S - 1) * C;
+            a1[q] = s1[16 * jt + 4 * q];
+            b1[q] = m1[o];
+            if (DUAL) { a2[q] = s2[16 * jt + 4 * q]; b2[q] = m2[o]; }
+        }
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b1[0], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b1[1], p1, 0, 0, 0);
+        if (DUAL) {
+            r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[0], b2[0], r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[1], b2[1], r1, 0, 0, 0);
+        }
+        p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[2], b1[2], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[3], b1[3], p1, 0, 0, 0);
+        if (DUAL) {
+            r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[2], b2[2], r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[3], b2[3], r1, 0, 0, 0);
+        }
+    }
+    o1 = p0 + p1;
+    if (DUAL) o2 = r0 + r1;
 }
 
 // ---------------------------------------------------------------------------- forward
@@ -42,8 +127,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ O, float* __restrict__ lse) {
     extern __shared__ __align__(16) float smem[];
     float* qs = smem;                    // [16][64] scaled queries
-    float* sc = smem + AT * 64;          // [16][SP]
-    const int SP = (S + 3) & ~3;
+    float* sc = smem + AT * 64;          // [16][SPP] scores, then probabilities
+    const int SPP = strip_pitch(S);
     const int t = threadIdx.x, r = t >> 4, c4 = t & 15;
     const int s0 = blockIdx.x * AT, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
     const long base = (long)b * S * C + h * 64;
@@ -52,39 +137,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     if (rv) qv = *reinterpret_cast<const float4*>(Q + base + (long)(s0 + r) * C + 4 * c4);
     *reinterpret_cast<float4*>(qs + r * 64 + 4 * c4) = make_float4(qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale);
     __syncthreads();
-    for (int j = t; j < S; j += 256) {
-        float4 kr[16];
-        load_row16(K + base + (long)j * C, kr);
-#pragma unroll
-        for (int rr = 0; rr < AT; ++rr) sc[rr * SP + j] = dot64(reinterpret_cast<const float4*>(qs + rr * 64), kr);
-    }
+    strip_mfma<false>(qs, K + base, nullptr, nullptr, S, C,
+                      [&](int m, int j, float v, float) { sc[m * SPP + j] = j < S ? v : 0.f; });
     __syncthreads();
     {   // softmax of row r by its 16 lanes
         float m = -INFINITY;
-        for (int j = c4; j < S; j += 16) m = fmaxf(m, sc[r * SP + j]);
+        for (int j = c4; j < S; j += 16) m = fmaxf(m, sc[r * SPP + j]);
         m = group16_max(m);
         float sum = 0.f;
         for (int j = c4; j < S; j += 16) {
-            const float e = expf(sc[r * SP + j] - m);
-            sc[r * SP + j] = e;
+            const float e = expf(sc[r * SPP + j] - m);
+            sc[r * SPP + j] = e;
             sum += e;
         }
         sum = group16_sum(sum);
         const float inv = 1.f / sum;
-        for (int j = c4; j < S; j += 16) sc[r * SP + j] *= inv;
+        for (int j = c4; j < S; j += 16) sc[r * SPP + j] *= inv;
         if (c4 == 0 && rv) lse[((long)b * H + h) * S + s0 + r] = m + logf(sum);
     }
     __syncthreads();
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < S; ++j) {
-        const float p = sc[r * SP + j];
-        const float4 vv = *reinterpret_cast<const float4*>(V + base + (long)j * C + 4 * c4);
-        acc.x = fmaf(p, vv.x, acc.x); acc.y = fmaf(p, vv.y, acc.y);
-        acc.z = fmaf(p, vv.z, acc.z); acc.w = fmaf(p, vv.w, acc.w);
+    floatx4 acc, unused;
+    out_mfma<false>(sc, V + base, nullptr, nullptr, S, C, acc, unused);
+    const int lane = t & 63, w = t >> 6, n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = s0 + 4 * g + reg;
+        if (row < S) {
+            const long o = base + (long)row * C + 16 * w + n;
+            O[o] = Q[o] + acc[reg];
+        }
     }
-    if (rv)
-        *reinterpret_cast<float4*>(O + base + (long)(s0 + r) * C + 4 * c4) =
-            make_float4(qv.x + acc.x, qv.y + acc.y, qv.z + acc.z, qv.w + acc.w);
 }
 
 // ---------------------------------------------------------------------------- backward, query side
@@ -97,9 +179,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     extern __shared__ __align__(16) float smem[];
     float* qs = smem;                    // [16][64] scaled queries
     float* ds = smem + AT * 64;          // [16][64] dO rows
-    float* sp = smem + 2 * AT * 64;      // [16][SP] P, then dS
-    const int SP = (S + 3) & ~3;
-    float* sd = sp + AT * SP;            // [16][SP] dP
+    float* sp = smem + 2 * AT * 64;      // [16][SPP] P, then dS
+    const int SPP = strip_pitch(S);
+    float* sd = sp + AT * SPP;           // [16][SPP] dP
     const int t = threadIdx.x, r = t >> 4, c4 = t & 15;
     const int s0 = blockIdx.x * AT, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
     const long base = (long)b * S * C + h * 64;
@@ -114,36 +196,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     __shared__ float row_lse[AT];
     if (t < AT) row_lse[t] = s0 + t < S ? lse[((long)b * H + h) * S + s0 + t] : 0.f;
     __syncthreads();
-    for (int j = t; j < S; j += 256) {
-        float4 kr[16];
-        load_row16(K + base + (long)j * C, kr);
-#pragma unroll
-        for (int rr = 0; rr < AT; ++rr)
-            sp[rr * SP + j] = expf(dot64(reinterpret_cast<const float4*>(qs + rr * 64), kr) - row_lse[rr]);
-        load_row16(V + base + (long)j * C, kr);
-#pragma unroll
-        for (int rr = 0; rr < AT; ++rr) sd[rr * SP + j] = dot64(reinterpret_cast<const float4*>(ds + rr * 64), kr);
-    }
+    strip_mfma<true>(qs, K + base, ds, V + base, S, C, [&](int m, int j, float v1, float v2) {
+        const bool in = j < S;
+        sp[m * SPP + j] = in ? expf(v1 - row_lse[m]) : 0.f;
+        sd[m * SPP + j] = in ? v2 : 0.f;
+    });
     __syncthreads();
     {
         float d = 0.f;
-        for (int j = c4; j < S; j += 16) d = fmaf(sp[r * SP + j], sd[r * SP + j], d);
+        for (int j = c4; j < S; j += 16) d = fmaf(sp[r * SPP + j], sd[r * SPP + j], d);
         d = group16_sum(d);
-        for (int j = c4; j < S; j += 16) sp[r * SP + j] *= sd[r * SP + j] - d;
+        for (int j = c4; j < S; j += 16) sp[r * SPP + j] *= sd[r * SPP + j] - d;
         if (c4 == 0 && rv) delta[((long)b * H + h) * S + s0 + r] = d;
     }
     __syncthreads();
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < S; ++j) {
-        const float p = sp[r * SP + j];
-        const float4 kk = *reinterpret_cast<const float4*>(K + base + (long)j * C + 4 * c4);
-        acc.x = fmaf(p, kk.x, acc.x); acc.y = fmaf(p, kk.y, acc.y);
-        acc.z = fmaf(p, kk.z, acc.z); acc.w = fmaf(p, kk.w, acc.w);
+    floatx4 acc, unused;
+    out_mfma<false>(sp, K + base, nullptr, nullptr, S, C, acc, unused);
+    const int lane = t & 63, w = t >> 6, n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = s0 + 4 * g + reg;
+        if (row < S) {
+            const long o = base + (long)row * C + 16 * w + n;
+            dQ[o] = fmaf(scale, acc[reg], dO[o]);
+        }
     }
-    if (rv)
-        *reinterpret_cast<float4*>(dQ + base + (long)(s0 + r) * C + 4 * c4) =
-            make_float4(fmaf(scale, acc.x, gv.x), fmaf(scale, acc.y, gv.y), fmaf(scale, acc.z, gv.z),
-                        fmaf(scale, acc.w, gv.w));
 }
 
 // ---------------------------------------------------------------------------- backward, key side
@@ -157,9 +234,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     extern __shared__ __align__(16) float smem[];
     float* ks = smem;                    // [16][64] keys, pre-scaled
     float* vs = smem + AT * 64;          // [16][64] values
-    float* pt = smem + 2 * AT * 64;      // [16][SP] P^T
-    const int SP = (S + 3) & ~3;
-    float* st = pt + AT * SP;            // [16][SP] dS^T
+    float* pt = smem + 2 * AT * 64;      // [16][SPP] P^T
+    const int SPP = strip_pitch(S);
+    float* st = pt + AT * SPP;           // [16][SPP] dS^T
     const int t = threadIdx.x, r = t >> 4, c4 = t & 15;
     const int j0 = blockIdx.x * AT, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
     const long base = (long)b * S * C + h * 64;
@@ -173,34 +250,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     *reinterpret_cast<float4*>(vs + r * 64 + 4 * c4) = vv;
     __syncthreads();
     const long sbase = ((long)b * H + h) * S;
-    for (int i = t; i < S; i += 256) {
-        float4 row[16];
-        float p[AT];
-        const float l = lse[sbase + i], d = delta[sbase + i];
-        load_row16(Q + base + (long)i * C, row);
-#pragma unroll
-        for (int jj = 0; jj < AT; ++jj) p[jj] = expf(dot64(reinterpret_cast<const float4*>(ks + jj * 64), row) - l);
-        load_row16(dO + base + (long)i * C, row);
-#pragma unroll
-        for (int jj = 0; jj < AT; ++jj) {
-            const float dp = dot64(reinterpret_cast<const float4*>(vs + jj * 64), row);
-            pt[jj * SP + i] = p[jj];
-            st[jj * SP + i] = p[jj] * (dp - d);
-        }
-    }
+    // transposed strips: row = key of this workgroup, column = query i
+    strip_mfma<true>(ks, Q + base, vs, dO + base, S, C, [&](int m, int i, float v1, float v2) {
+        const bool in = i < S;
+        const int ic = in ? i : S - 1;
+        const float p = in ? expf(v1 - lse[sbase + ic]) : 0.f;
+        pt[m * SPP + i] = p;
+        st[m * SPP + i] = in ? p * (v2 - delta[sbase + ic]) : 0.f;
+    });
     __syncthreads();
-    float4 av = make_float4(0.f, 0.f, 0.f, 0.f), ak = av;
-    for (int i = 0; i < S; ++i) {
-        const float p = pt[r * SP + i], s = st[r * SP + i];
-        const float4 g = *reinterpret_cast<const float4*>(dO + base + (long)i * C + 4 * c4);
-        const float4 q = *reinterpret_cast<const float4*>(Q + base + (long)i * C + 4 * c4);
-        av.x = fmaf(p, g.x, av.x); av.y = fmaf(p, g.y, av.y); av.z = fmaf(p, g.z, av.z); av.w = fmaf(p, g.w, av.w);
-        ak.x = fmaf(s, q.x, ak.x); ak.y = fmaf(s, q.y, ak.y); ak.z = fmaf(s, q.z, ak.z); ak.w = fmaf(s, q.w, ak.w);
-    }
-    if (rv) {
-        *reinterpret_cast<float4*>(dV + base + (long)(j0 + r) * C + 4 * c4) = av;
-        *reinterpret_cast<float4*>(dK + base + (long)(j0 + r) * C + 4 * c4) =
-            make_float4(scale * ak.x, scale * ak.y, scale * ak.z, scale * ak.w);
+    floatx4 av, ak;
+    out_mfma<true>(pt, dO + base, st, Q + base, S, C, av, ak);
+    const int lane = t & 63, w = t >> 6, n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = j0 + 4 * g + reg;
+        if (row < S) {
+            const long o = base + (long)row * C + 16 * w + n;
+            dV[o] = av[reg];
+            dK[o] = scale * ak[reg];
+        }
     }
 }
 
@@ -231,8 +300,7 @@ extern "C" int cmvae_attention_fwd(const float* Q, const float* K, const float* 
     cmvae::clear_stale_error();
     CMVAE_REQUIRE(Q && K && V && O && lse, "cmvae_attention_fwd: NULL argument");
     if (int e = check_attn("cmvae_attention_fwd", B, S, heads)) return e;
-    const int SP = (S + 3) & ~3;
-    const size_t lds = (size_t)(AT * 64 + AT * SP) * sizeof(float);
+    const size_t lds = (size_t)(AT * 64 + AT * strip_pitch(S)) * sizeof(float);
     allow_large_lds();
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + AT - 1) / AT, heads, B), dim3(256), lds, (hipStream_t)stream, Q, K, V,
                        S, heads * 64, scale, O, lse);
@@ -245,8 +313,7 @@ extern "C" int cmvae_attention_bwd(const float* Q, const float* K, const float* 
     cmvae::clear_stale_error();
     CMVAE_REQUIRE(Q && K && V && lse && dO && dQ && dK && dV && delta, "cmvae_attention_bwd: NULL argument");
     if (int e = check_attn("cmvae_attention_bwd", B, S, heads)) return e;
-    const int SP = (S + 3) & ~3;
-    const size_t lds = (size_t)(2 * AT * 64 + 2 * AT * SP) * sizeof(float);
+    const size_t lds = (size_t)(2 * AT * 64 + 2 * AT * strip_pitch(S)) * sizeof(float);
     allow_large_lds();
     const dim3 grid((S + AT - 1) / AT, heads, B);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds, (hipStream_t)stream, Q, K, V, lse, dO, S,

@@ -818,15 +818,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         part[(long)blockIdx.x * cols + c] = s0 + s1;
     }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols,
-                                                           float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * cols + c];
-    out[c] = s;
-}
-
 constexpr int COLSUM_BLOCKS = 256;
 
 }  // namespace cmvae
@@ -900,8 +891,7 @@ extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, con
             const int nb = rows < COLSUM_BLOCKS ? rows : COLSUM_BLOCKS;
             hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, dZ, rows, out_f, dz_pitch, cs_part);
             if (int e = check_launch("colsum_partial_kernel")) return e;
-            hipLaunchKernelGGL(colsum_final_kernel, dim3((out_f + 255) / 256), dim3(256), 0, st, cs_part, nb, out_f, db);
-            if (int e = check_launch("colsum_final_kernel")) return e;
+            if (int e = cmvae_colsum_reduce(cs_part, nb, out_f, db, stream)) return e;
         }
     }
     return 0;

@@ -103,7 +103,8 @@ def test_flat_adam_matches_torch_adam():
         assert _rel(d, r) < 1e-6
 
 
-@pytest.mark.parametrize('B,S,heads', [(2, 5, 4), (3, 37, 4), (4, 300, 4), (1, 16, 1), (2, 600, 2)])
+@pytest.mark.parametrize('B,S,heads', [(2, 5, 4), (3, 37, 4), (4, 300, 4), (1, 16, 1), (2, 600, 2), (2, 1, 4),
+                                         (1, 1024, 1), (1, 17, 2)])
 def test_attention_core(B, S, heads):
     """O = Q + softmax(QK^T * scale) V per head, forward and all three gradients (omniglot/module.py:92-99)."""
     from cmvae_amd.linear import attention
