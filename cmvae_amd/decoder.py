@@ -196,9 +196,36 @@ class _DecoderBCE(torch.autograd.Function):
 
 
 # proj output column (pix*64 + c)  <-  reference column (c*4 + pix): channels-last view of [64,2,2]
-def nhwc_perm(device):
-    j = torch.arange(256, device=device)
-    return (j % 64) * 4 + j // 64
+_PERMS = {}
+
+
+def nhwc_perm(device, hidden=64):
+    """(perm, inverse) index tensors, built once per device: channels-last column j = pix*hidden + c takes the
+    reference's column c*4 + pix."""
+    key = (str(device), hidden)
+    if key not in _PERMS:
+        j = torch.arange(4 * hidden, device=device)
+        perm = (j % hidden) * 4 + j // hidden
+        _PERMS[key] = (perm, torch.argsort(perm))
+    return _PERMS[key]
+
+
+class _Permute(torch.autograd.Function):
+    """x.index_select(dim, perm) for a permutation: the backward is the gather by the inverse permutation (one
+    kernel each way, instead of advanced indexing's sort-based index_put)."""
+
+    @staticmethod
+    def forward(ctx, x, dim, perm, inv):
+        ctx.dim, ctx.inv = dim, inv
+        return x.index_select(dim, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.index_select(ctx.dim, ctx.inv), None, None, None
+
+
+def permute(x, dim, perm, inv):
+    return _Permute.apply(x, dim, perm, inv)
 
 
 def decoder_bce(decoder, h_rec_nhwc, target, M):

@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import ops
 from .module import OmniglotEncoder, OmniglotDecoder, SAB, CausalEncoder
 from .linear import linear
-from .decoder import decoder_bce, nhwc_perm
+from .decoder import decoder_bce, nhwc_perm, permute
 
 _LOG_NORM = -0.5 * np.log(2 * np.pi)
 
@@ -60,7 +60,9 @@ class _GMVAEBase(nn.Module):
 
     def gaussian_log_prob(self, x, mean, logvar=None):
         if logvar is None:
-            logvar = torch.zeros_like(mean)
+            # the reference builds a zeros tensor and runs the general formula (omniglot/model.py:89-95); with
+            # logvar = 0 that is 0 + a/1 = a bit for bit, so the four extra elementwise passes are skipped
+            return (-0.5 * (x - mean).pow(2) + self.log_norm_constant).sum(dim=-1)
         return (-0.5 * (logvar + (x - mean).pow(2) / logvar.exp()) + self.log_norm_constant).sum(dim=-1)
 
     def h_a(self, A):
@@ -110,8 +112,15 @@ class _GMVAEBase(nn.Module):
             q_eps_mu_k, torch.log(trace_k)[:, :, None].expand(-1, -1, self.latent_size))
         log_p_z = ops.mixture_loglik(q_z, mu_k, logw)                      # [B, N]
         log_q_z = q_z4_logq                                                # [B, S, M]
-        log_p_eps = (-0.5 * q_eps.pow(2) + self.log_norm_constant).sum(-1)  # glp(q_eps, 0)
-        kl_loss = log_q_z.mean() - log_p_z.mean() - log_p_eps.mean()
+        if extras is None:
+            # mean over rows of glp(q_eps, 0) = -0.5 * sum(q_eps^2) / rows + D*c: one reduction instead of four passes
+            log_p_eps = None
+            log_p_eps_mean = -0.5 * torch.linalg.vector_norm(q_eps).pow(2) / (q_eps.numel() // self.latent_size) \
+                + self.latent_size * _LOG_NORM
+        else:
+            log_p_eps = (-0.5 * q_eps.pow(2) + self.log_norm_constant).sum(-1)  # glp(q_eps, 0)
+            log_p_eps_mean = log_p_eps.mean()
+        kl_loss = log_q_z.mean() - log_p_z.mean() - log_p_eps_mean
         h = self.h_a(A)
         h_augment = h_lambda * h + 0.5 * h_c * h * h + a_lambda * A.abs().sum()
         if extras is not None:
@@ -200,8 +209,8 @@ class OmniglotGMVAE(_GMVAEBase):
         h = torch.cat([q_z, q_eps], -1).view(-1, 2 * D)
         h = linear(h, self.proj[0].weight, self.proj[0].bias, 'elu')
         h = linear(h, self.proj[2].weight, self.proj[2].bias, 'elu')
-        perm = nhwc_perm(h.device)
-        H_rec = linear(h, self.proj[4].weight[perm], self.proj[4].bias[perm], 'elu')
+        perm, inv = nhwc_perm(h.device, self.hidden_size)
+        H_rec = linear(h, permute(self.proj[4].weight, 0, perm, inv), permute(self.proj[4].bias, 0, perm, inv), 'elu')
         # decoder + Bernoulli likelihood: one fused HIP pipeline (cmvae_amd/decoder.py)
         p_rec, bce_sum = decoder_bce(self.decoder, H_rec, X.reshape(B * S, -1), M)
         X_rec = p_rec.view(B, S, M, *self.input_shape)
@@ -229,8 +238,8 @@ class OmniglotGMVAE(_GMVAEBase):
         h = torch.cat([z, self.causal(z)], -1).view(-1, 2 * D)
         h = linear(h, self.proj[0].weight, self.proj[0].bias, 'elu')
         h = linear(h, self.proj[2].weight, self.proj[2].bias, 'elu')
-        perm = nhwc_perm(h.device)
-        H_rec = linear(h, self.proj[4].weight[perm], self.proj[4].bias[perm], 'elu')
+        perm, inv = nhwc_perm(h.device, self.hidden_size)
+        H_rec = linear(h, permute(self.proj[4].weight, 0, perm, inv), permute(self.proj[4].bias, 0, perm, inv), 'elu')
         p, _ = decoder_bce(self.decoder, H_rec, torch.zeros(H_rec.shape[0], 784, device=z.device), 1)
         return p.view(-1, *self.input_shape)
 

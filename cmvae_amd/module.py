@@ -50,10 +50,10 @@ class OmniglotEncoder(nn.Module):
     def forward(self, x):
         """x [n,1,28,28] (or [n,784]) -> [n, 4*hidden] in the reference's c*4+pix column order."""
         from .encoder import encode_images
+        from .decoder import nhwc_perm, permute
         H = encode_images(self, x.reshape(x.shape[0], -1))
-        j = torch.arange(self.last_hidden_size, device=H.device)
-        hs = self.last_hidden_size // 4
-        return H[:, (j % 4) * hs + j // 4]
+        perm, inv = nhwc_perm(H.device, self.last_hidden_size // 4)
+        return permute(H, 1, inv, perm)          # reference column c*4 + pix takes channels-last column pix*hs + c
 
 
 class OmniglotDecoder(nn.Module):
