@@ -155,3 +155,32 @@ def test_component_count_limits(device, K_, N_):
     assert rel_err(mu, rmu) < RTOL and rel_err(pi, rpi) < RTOL
     with pytest.raises(RuntimeError):
         ops.unsup_prior(z.to(device), torch.zeros(2, 33, dtype=torch.int64, device=device), c, 1, False, 1.0)
+
+
+def test_em_sweep_batch_is_independent_of_the_tile_partition(device):
+    """Evaluation-sweep shape (hundreds of episodes per launch: 3 workgroups per episode, many tiles each) against the
+    same episodes run 4 at a time (one tile per workgroup): the semi-supervised EM must not depend on how an
+    episode's tiles are dealt to workgroups (only the order of the partial sums changes)."""
+    from cmvae_amd import ops
+    from tests.test_gpu_kernels import _causal_desc
+    Bs, Nu, Ns, Ks = 260, 2500, 320, 5
+    model, _ = build_pair('feat', K=Ks, linear=True)
+    c = _causal_desc(model, device)
+    g = torch.Generator().manual_seed(17)
+    centers = torch.randn(Bs, Ks, 64, generator=g) * 2.0
+    lab_u = torch.randint(0, Ks, (Bs, Nu), generator=g)
+    uz = (centers.gather(1, lab_u[..., None].expand(-1, -1, 64)) + torch.randn(Bs, Nu, 64, generator=g)).to(device)
+    y = torch.arange(Ns).remainder(Ks)[None].repeat(Bs, 1)
+    sz = (centers.gather(1, y[..., None].expand(-1, -1, 64)) + torch.randn(Bs, Ns, 64, generator=g)).to(device)
+    y = y.to(device)
+    big = ops.semi_prior(uz, sz, y, Ks, c, 4, model.gamma1)
+    for b0 in (0, 128, 256):
+        small = ops.semi_prior(uz[b0:b0 + 4].contiguous(), sz[b0:b0 + 4].contiguous(), y[b0:b0 + 4].contiguous(), Ks, c,
+                               4, model.gamma1)
+        for t_big, t_small in zip(big, small):
+            assert rel_err(t_big[b0:b0 + 4], t_small) < 1e-5
+    # the mixture log-likelihood pass shares the partition
+    logw = big[-1]
+    lp_big = ops.mixture_loglik(uz, big[1], logw)
+    lp_small = ops.mixture_loglik(uz[:4].contiguous(), big[1][:4].contiguous(), logw[:4].contiguous())
+    assert rel_err(lp_big[:4], lp_small) < 1e-6
