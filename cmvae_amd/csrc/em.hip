@@ -800,9 +800,11 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(const float* __re
 // Split every episode's tiles over as many workgroups as stay resident at once (3 per CU on 256 CUs; the em_pass
 // instantiations for K > 16 and the dz variant hold 2 per CU, their second round is a short one): a single
 // workgroup per CU would serialise its own load -> E-step -> M-step phases with nothing to overlap them.
-static int pick_tiles_per_block(int B, int N) {
+static int pick_tiles_per_block(int B, int N, int K, bool dz = false) {
     const int tiles_ep = (N + TRP - 1) / TRP;
-    int nblk = (768 + B - 1) / B;                       // workgroups per episode
+    const int resident = (K <= 16 && !dz) ? 768 : 512;
+    int nblk = resident / B;                             // workgroups per episode: at most one resident round
+    if (nblk < 1) nblk = 1;
     if (nblk > tiles_ep) nblk = tiles_ep;
     if (nblk < 1) nblk = 1;
     return (tiles_ep + nblk - 1) / nblk;
@@ -872,14 +874,14 @@ static EmWorkspace carve(void* base, int B, int Nu, int Ns, int K, bool semi) {
         off += align_up(nfloat * sizeof(float));
         return p;
     };
-    const int tpb = pick_tiles_per_block(B, Nu), nblk = nblk_for(Nu, tpb);
+    const int tpb = pick_tiles_per_block(B, Nu, K), nblk = nblk_for(Nu, tpb);
     w.minv0 = take(D * D);
     w.minv = take(semi ? (size_t)B * K * D * D : D * D);
     w.part_N = take((size_t)B * nblk * 32);
     w.part_S1 = take((size_t)B * nblk * K * D);
     if (semi) {
         w.part_S2 = take((size_t)B * nblk * K * D);
-        const int stpb = pick_tiles_per_block(B, Ns), snblk = nblk_for(Ns, stpb);
+        const int stpb = pick_tiles_per_block(B, Ns, K), snblk = nblk_for(Ns, stpb);
         w.spart_N = take((size_t)B * snblk * 32);
         w.spart_S1 = take((size_t)B * snblk * K * D);
         w.spart_S2 = take((size_t)B * snblk * K * D);
@@ -934,7 +936,7 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
     CMVAE_REQUIRE(workspace && workspace_bytes >= w.bytes, "cmvae_unsup_prior: workspace %zu < %zu", workspace_bytes,
                   w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    const int tpb = pick_tiles_per_block(B, N), nblk = nblk_for(N, tpb);
+    const int tpb = pick_tiles_per_block(B, N, K), nblk = nblk_for(N, tpb);
     // initial inverse (tau0 = 1) and the loop inverse (tau = gamma1); both data independent
     if (int e = launch_gram_inverse(nullptr, 1.0f, 1, *c, w.minv0, st)) return e;
     const float* minv_loop = w.minv0;
@@ -971,7 +973,7 @@ extern "C" int cmvae_em_pass(const float* z, const float* mu, const float* logw,
                   w.bytes);
     PassArgs p{};
     p.z = z; p.mu = mu; p.logw = logw; p.part_N = w.part_N; p.part_S1 = w.part_S1;
-    p.N = N; p.K = K; p.tiles_per_block = pick_tiles_per_block(B, N); p.nblk = nblk_for(N, p.tiles_per_block);
+    p.N = N; p.K = K; p.tiles_per_block = pick_tiles_per_block(B, N, K); p.nblk = nblk_for(N, p.tiles_per_block);
     if (nblk_out) *nblk_out = p.nblk;
     return launch_pass(p, B, (hipStream_t)stream);
 }
@@ -993,8 +995,8 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
     CMVAE_REQUIRE(workspace && workspace_bytes >= w.bytes, "cmvae_semi_prior: workspace %zu < %zu", workspace_bytes,
                   w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    const int tpb = pick_tiles_per_block(B, Nu), nblk = nblk_for(Nu, tpb);
-    const int stpb = pick_tiles_per_block(B, Ns), snblk = nblk_for(Ns, stpb);
+    const int tpb = pick_tiles_per_block(B, Nu, K), nblk = nblk_for(Nu, tpb);
+    const int stpb = pick_tiles_per_block(B, Ns, K), snblk = nblk_for(Ns, stpb);
     // supervised sums (constant over the loop): y^T sz, y^T sz^2, sum y
     PassArgs s{};
     s.z = sz; s.labels = y; s.part_N = w.spart_N; s.part_S1 = w.spart_S1; s.part_S2 = w.spart_S2;
@@ -1041,8 +1043,7 @@ extern "C" int cmvae_posterior_argmax(const float* z, const float* mu, const flo
 }
 
 extern "C" size_t cmvae_mixture_workspace_bytes(int B, int N, int K) {
-    (void)K;
-    const int tpb = pick_tiles_per_block(B, N), nblk = nblk_for(N, tpb);
+    const int tpb = pick_tiles_per_block(B, N, K), nblk = nblk_for(N, tpb);
     return align_up((size_t)B * nblk * 32 * sizeof(float));
 }
 
@@ -1053,7 +1054,7 @@ extern "C" int cmvae_mixture_loglik_fwd(const float* z, const float* mu, const f
     CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX, "cmvae_mixture_loglik_fwd: bad shape");
     PassArgs p{};
     p.z = z; p.mu = mu; p.logw = logw; p.lse = lse; p.N = N; p.K = K;
-    p.tiles_per_block = pick_tiles_per_block(B, N); p.nblk = nblk_for(N, p.tiles_per_block);
+    p.tiles_per_block = pick_tiles_per_block(B, N, K); p.nblk = nblk_for(N, p.tiles_per_block);
     return launch_pass(p, B, (hipStream_t)stream);
 }
 
@@ -1067,7 +1068,7 @@ extern "C" int cmvae_mixture_loglik_bwd(const float* z, const float* mu, const f
                   "cmvae_mixture_loglik_bwd: workspace too small");
     PassArgs p{};
     p.z = z; p.mu = mu; p.logw = logw; p.g = g; p.dz = dz; p.part_N = (float*)workspace; p.N = N; p.K = K;
-    p.tiles_per_block = pick_tiles_per_block(B, N); p.nblk = nblk_for(N, p.tiles_per_block);
+    p.tiles_per_block = pick_tiles_per_block(B, N, K); p.nblk = nblk_for(N, p.tiles_per_block);
     if (int e = launch_pass(p, B, (hipStream_t)stream)) return e;
     hipLaunchKernelGGL(partn_reduce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, p.nblk,
                        K, dlogw);
