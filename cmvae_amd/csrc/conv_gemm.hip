@@ -441,6 +441,154 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
     }
 }
 
+// ---------------------------------------------------------------------------- forward, weight-stationary variant
+// For launches WITH the folded BatchNorm and at most 4 taps (the sub-pixel phases of the decoder's transposed
+// convolutions): all taps' 64x64 weight tiles sit in LDS for the whole launch (<= 68 KB, two workgroups per CU) and
+// the operand comes straight from global memory in fragment layout, as in the direct kernel, with BatchNorm + ReLU
+// applied to the registers.  Nothing in the main loop is shared between waves, so it has NO block barrier: the four
+// waves of a workgroup drift apart and fill each other's load / epilogue bubbles.
+constexpr int WSTAT_TAPS = 4;
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void conv_gemm_wstat_kernel(ConvGeom g, const float* __restrict__ A,
+                                                                 const float* __restrict__ Wt,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ a_scale,
+                                                                 const float* __restrict__ a_shift,
+                                                                 float* __restrict__ out,
+                                                                 float* __restrict__ stats_part, int stats_rows) {
+    extern __shared__ __align__(16) float wstat_smem[];
+    float* Ws = wstat_smem;                                        // [ntaps][64][LDA]
+    int* opix = reinterpret_cast<int*>(Ws + g.ntaps * 64 * LDA);   // [2][4 waves][32 rows]
+    float* red = reinterpret_cast<float*>(opix + 2 * 4 * 32);      // [4][128]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int q = tid & 15, rb = tid >> 4;
+    const int nb = blockIdx.y;
+    {
+        const float* Wn = Wt + nb * g.w_nblk_stride + (long)rb * g.w_pitch + 4 * q;
+        const long w16 = 16L * g.w_pitch;
+        for (int t = 0; t < g.ntaps; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<float4*>(&Ws[(t * 64 + rb + 16 * e) * LDA + 4 * q]) =
+                    *reinterpret_cast<const float4*>(Wn + g.w_off[t] + e * w16);
+    }
+    // BatchNorm fold of this lane's channels (8kk + 4h .. +3)
+    float4 sc[8], sh[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        sc[kk] = *reinterpret_cast<const float4*>(a_scale + 8 * kk + 4 * h);
+        sh[kk] = *reinterpret_cast<const float4*>(a_shift + 8 * kk + 4 * h);
+    }
+    const int ntiles = (g.rows_total + BM - 1) / BM;
+    const int nsteps = ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * g.ntaps;
+    const RowDecoder dec(g);
+    float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
+    const float b0 = bias ? bias[nb * 64 + i] : 0.f;
+    const float b1 = bias ? bias[nb * 64 + 32 + i] : 0.f;
+    __syncthreads();                                               // the only barrier before the statistics
+
+    RowInfo ri;
+    float4 ra[8];
+    bool ok_next = false;
+    int ltile = blockIdx.x, par = 0;
+    auto rows_of_tile = [&](int tile, int* op) {                   // op: this wave's 32 output pixels
+        const int r = tile * BM + 32 * w + i;                      // this lane's row
+        int opx = -1;
+        dec.decode<1>(r, 0, [&](int, int n, int y, int x) {
+            ri = make_row(g, r, n, y, x);
+            if (r < g.rows_total) opx = (n * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
+        });
+        if (h == 0) op[i] = opx;
+    };
+    auto load_frag = [&](int t) {                                  // raw loads: the fold is applied when consumed
+        const int dy = g.dy[t], dx = g.dx[t];
+        const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[t];
+        ok_next = ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
+        const float* p = A + (ok_next ? ri.off + delta : 0) + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) ra[kk] = *reinterpret_cast<const float4*>(p + 8 * kk);
+    };
+    rows_of_tile(ltile, opix + w * 32);
+    load_frag(0);
+    floatx16 acc0 = {}, acc1 = {};
+    int t = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        float4 a[8];
+        {
+            const bool ok = ok_next;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<true>(ra[kk], ok, sc[kk], sh[kk]);
+        }
+        int tn = t + 1;
+        if (tn == g.ntaps) {
+            tn = 0;
+            ltile += gridDim.x;
+            rows_of_tile(ltile, opix + ((par ^ 1) * 4 + w) * 32);
+        }
+        load_frag(tn);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* bp0 = &Ws[(t * 64 + i) * LDA + 4 * h];
+        const float* bp1 = bp0 + 32 * LDA;
+        float4 p4 = *reinterpret_cast<const float4*>(bp0);
+        float4 r4 = *reinterpret_cast<const float4*>(bp1);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float4 pn = p4, rn = r4;
+            if (kk < 7) {
+                pn = *reinterpret_cast<const float4*>(bp0 + 8 * kk + 8);
+                rn = *reinterpret_cast<const float4*>(bp1 + 8 * kk + 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 a4 = a[kk];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, p4.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, r4.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, p4.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, r4.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, p4.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, r4.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, p4.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
+            p4 = pn; r4 = rn;
+        }
+        if (tn == 0) {
+            const int* op_w = opix + (par * 4 + w) * 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int op = op_w[(reg & 3) + 8 * (reg >> 2) + 4 * h];
+                if (op >= 0) {
+                    const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
+                    ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
+                    ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
+                    float* o = out + (long)op * g.o_pitch + nb * 64;
+                    o[i] = apply_act<ACT>(v0);
+                    o[32 + i] = apply_act<ACT>(v1);
+                }
+            }
+            acc0 = floatx16{};
+            acc1 = floatx16{};
+            par ^= 1;
+        }
+        t = tn;
+    }
+    if (stats_part) {
+        ssum0 += __shfl_xor(ssum0, 32); ssum1 += __shfl_xor(ssum1, 32);
+        ssq0 += __shfl_xor(ssq0, 32); ssq1 += __shfl_xor(ssq1, 32);
+        if (h == 0) {
+            red[w * 128 + i] = ssum0; red[w * 128 + 32 + i] = ssum1;
+            red[w * 128 + 64 + i] = ssq0; red[w * 128 + 96 + i] = ssq1;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float v = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            stats_part[(long)blockIdx.x * 128 + tid] = v;
+            // the caller sized the partials for cmvae_conv_gemm_grid() workgroups: the rows this launch does not
+            // own (it runs fewer, two per CU) are zeroed
+            for (int r = blockIdx.x + gridDim.x; r < stats_rows; r += gridDim.x) stats_part[(long)r * 128 + tid] = 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- weight gradient
 // part[blk][t][ci][co] = sum_r T(A[src(r,t)])[ci] * G[outpix(r)][g_col + co]
 // Same software pipeline as the forward kernel: while the 64 MFMAs of a tap run, the next tap's operand rows (or
@@ -687,6 +835,25 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
             default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
         }
         return check_launch("conv_gemm_direct_kernel");
+    }
+    if (g.ntaps <= WSTAT_TAPS) {   // folded BatchNorm, few taps: weights stay in LDS for the whole launch
+        const size_t lds = (size_t)g.ntaps * 64 * LDA * sizeof(float) + 2 * 4 * 32 * sizeof(int) + 4 * 128 * sizeof(float);
+        static const bool opted = [] {
+            const int cap = WSTAT_TAPS * 64 * LDA * (int)sizeof(float) + 4096;
+            (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            (void)hipGetLastError();
+            return true;
+        }();
+        (void)opted;
+        dim3 wgrid(grid.x < 512 ? grid.x : 512, n_col_blocks);     // two resident workgroups per CU
+        switch (act) {
+            case 0: hipLaunchKernelGGL((conv_gemm_wstat_kernel<0>), wgrid, dim3(256), lds, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part, (int)grid.x); break;
+            case 1: hipLaunchKernelGGL((conv_gemm_wstat_kernel<1>), wgrid, dim3(256), lds, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part, (int)grid.x); break;
+            default: hipLaunchKernelGGL((conv_gemm_wstat_kernel<2>), wgrid, dim3(256), lds, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part, (int)grid.x); break;
+        }
+        return check_launch("conv_gemm_wstat_kernel");
     }
 #define CMVAE_LAUNCH_GEMM(ACT)                                                                                  \
     if (a_scale)                                                                                                \
