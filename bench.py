@@ -115,9 +115,10 @@ def pmc_traffic(select):
 
 
 def pmc_traffic_conv_gemm():
-    """The conv launches of conv_gemm_kernel / conv_gemm_direct_kernel (last template argument LINEAR = false:
-    the launches roofline_conv_gemm times)."""
-    return pmc_traffic(lambda k: k.startswith(('conv_gemm_kernel', 'conv_gemm_direct_kernel')) and k.endswith('false>'))
+    """The conv launches of conv_gemm_wstat_kernel / conv_gemm_direct_kernel / conv_gemm_kernel (the last two with
+    template argument LINEAR = false): the launches roofline_conv_gemm times."""
+    return pmc_traffic(lambda k: k.startswith('conv_gemm_wstat_kernel') or
+                       (k.startswith(('conv_gemm_kernel', 'conv_gemm_direct_kernel')) and k.endswith('false>')))
 
 
 def roofline_conv_gemm(step_fn):
@@ -148,7 +149,7 @@ def roofline_conv_gemm(step_fn):
     total_flops = sum(f for _, _, f in rec)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     traffic, src = pmc_traffic_conv_gemm()
-    return {'kernel': 'conv_gemm_kernel + conv_gemm_direct_kernel (conv / conv-transpose / data-gradient launches)', 'bound': 'mfma',
+    return {'kernel': 'conv_gemm_wstat_kernel + conv_gemm_direct_kernel (conv / conv-transpose / data-gradient launches)', 'bound': 'mfma',
             'achieved': round(achieved, 2),
             'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': src,
