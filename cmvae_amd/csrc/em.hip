@@ -204,12 +204,12 @@ __device__ __forceinline__ void gauss_jordan_wave(float (&own)[D], float* prow2,
 #endif
 }
 
-__global__ __launch_bounds__(256) void gram_inverse_kernel(float* __restrict__ out) {
-    __shared__ __align__(16) float CT[D * D];       // CT[j][i] = C[i][j]
-    __shared__ __align__(16) float Ms[D * MS_LD];
-    __shared__ __align__(16) float prow2[2 * D];
+// body of the Gram + inverse step for one matrix; the whole 256-thread workgroup calls it with >= 8384 floats of LDS
+__device__ __forceinline__ void gram_inverse_body(float* lds, float* __restrict__ o) {
+    float* CT = lds;                    // [64][64]  CT[j][i] = C[i][j]
+    float* Ms = lds + D * D;            // [64][MS_LD]
+    float* prow2 = Ms + D * MS_LD;      // [2][64]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float* o = out + (size_t)blockIdx.x * D * D;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         reinterpret_cast<float4*>(CT)[tid + 256 * i] = reinterpret_cast<const float4*>(o)[tid + 256 * i];
@@ -242,11 +242,22 @@ __global__ __launch_bounds__(256) void gram_inverse_kernel(float* __restrict__ o
 #pragma unroll
     for (int cc = 0; cc < D; ++cc) o[cc * D + lane] = own[cc] * rs;
 }
+constexpr int GRAM_LDS_FLOATS = D * D + D * MS_LD + 2 * D;
+
+__global__ __launch_bounds__(256) void gram_inverse_kernel(float* __restrict__ out) {
+    __shared__ __align__(16) float lds[GRAM_LDS_FLOATS];
+    gram_inverse_body(lds, out + (size_t)blockIdx.x * D * D);
+}
+
+static int launch_causal_diag(const float* logvar, float s0, int nmat, const cmvae_causal& c, float* out,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(causal_diag_kernel, dim3(16, nmat), dim3(256), 0, st, logvar, s0, c, out);
+    return check_launch("causal_diag_kernel");
+}
 
 static int launch_gram_inverse(const float* logvar, float s0, int nmat, const cmvae_causal& c, float* out,
                                hipStream_t st) {
-    hipLaunchKernelGGL(causal_diag_kernel, dim3(16, nmat), dim3(256), 0, st, logvar, s0, c, out);
-    if (int e = check_launch("causal_diag_kernel")) return e;
+    if (int e = launch_causal_diag(logvar, s0, nmat, c, out, st)) return e;
     hipLaunchKernelGGL(gram_inverse_kernel, dim3(nmat), dim3(256), 0, st, out);
     return check_launch("gram_inverse_kernel");
 }
@@ -267,6 +278,10 @@ struct PassArgs {
     float* lse;            // [B,N] or null
     float* dz;             // [B,N,64] or null
     int N, K, tiles_per_block, nblk;
+    // side job (semi-supervised loop): the grid's last side_rows rows invert side_nmat matrices whose C^T sits in
+    // side_out (gram_inverse_body) while the other rows run the pass -- the two are independent
+    float* side_out;
+    int side_nmat, side_rows;
 };
 
 // responsibilities of a 64-row tile: on entry lls[row][k] holds the joint log-likelihoods; on exit the
@@ -323,6 +338,15 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
     __shared__ __align__(16) float mus[KP * MP];
     __shared__ float Rs[TRP * RL];
     __shared__ float lws[KP];
+    if constexpr (MOM2 && !DZ) {
+        static_assert(TRP * ZS_LD >= GRAM_LDS_FLOATS, "the side job borrows the tile buffer");
+        const int pass_rows = (int)gridDim.y - a.side_rows;
+        if ((int)blockIdx.y >= pass_rows) {              // uniform per workgroup
+            const int m = ((int)blockIdx.y - pass_rows) * (int)gridDim.x + (int)blockIdx.x;
+            if (m < a.side_nmat) gram_inverse_body(zs, a.side_out + (size_t)m * D * D);
+            return;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.y, blk = blockIdx.x;
     const int N = a.N, K = a.K;
@@ -832,7 +856,7 @@ static int dispatch_kq(int K, F&& f) {
 
 template <int KH>
 static void launch_pass_kh(const PassArgs& a, int B, hipStream_t st) {
-    const dim3 grid(a.nblk, B);
+    const dim3 grid(a.nblk, B + (a.part_S2 && !a.dz ? a.side_rows : 0));
     if (a.dz) hipLaunchKernelGGL((em_pass_kernel<KH, false, true>), grid, dim3(256), 0, st, a);
     else if (a.part_S2) hipLaunchKernelGGL((em_pass_kernel<KH, true, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((em_pass_kernel<KH, false, false>), grid, dim3(256), 0, st, a);
@@ -1017,9 +1041,11 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
     p.N = Nu; p.K = K; p.tiles_per_block = tpb; p.nblk = nblk;
     f.init = 0; f.part_N = w.part_N; f.part_S1 = w.part_S1; f.part_S2 = w.part_S2; f.nblk = nblk;
     f.minv = w.minv; f.minv_stride = (size_t)D * D; f.tau_new = gamma1;
+    p.side_out = w.minv; p.side_nmat = B * K; p.side_rows = (B * K + nblk - 1) / nblk;
     for (int it = 0; it < iters; ++it) {
         // inverse from the incoming logvar and tau = gamma1 (omniglot/model.py:259-265)
-        if (int e = launch_gram_inverse(logvar, gamma1, B * K, *c, w.minv, st)) return e;
+        // C^T of every (episode, component), then ONE launch for the Gram inverses and the E/M pass (independent)
+        if (int e = launch_causal_diag(logvar, gamma1, B * K, *c, w.minv, st)) return e;
         if (int e = launch_pass(p, B, st)) return e;
         hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
         if (int e = check_launch("em_finalize_kernel")) return e;
