@@ -442,46 +442,46 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 }
 
 // ---------------------------------------------------------------------------- forward, weight-stationary variant
-// For launches WITH the folded BatchNorm and at most 4 taps (the sub-pixel phases of the decoder's transposed
-// convolutions): all taps' 64x64 weight tiles sit in LDS for the whole launch (<= 68 KB, two workgroups per CU) and
-// the operand comes straight from global memory in fragment layout, as in the direct kernel, with BatchNorm + ReLU
-// applied to the registers.  Nothing in the main loop is shared between waves, so it has NO block barrier: the four
+// The weight tiles of ALL taps of the launch sit in LDS for its whole duration and the operand comes straight from
+// global memory in fragment layout (as in the direct kernel), with the folded BatchNorm + ReLU applied on the
+// registers when there is one.  Nothing in the main loop is shared between waves, so it has NO block barrier: the
 // waves of a workgroup drift apart and fill each other's load / epilogue bubbles.
-constexpr int WSTAT_TAPS = 4;
-template <int ACT>
-__global__ __launch_bounds__(256, 2) void conv_gemm_wstat_kernel(ConvGeom g, const float* __restrict__ A,
-                                                                 const float* __restrict__ Wt,
-                                                                 const float* __restrict__ bias,
-                                                                 const float* __restrict__ a_scale,
-                                                                 const float* __restrict__ a_shift,
-                                                                 float* __restrict__ out,
-                                                                 float* __restrict__ stats_part, int stats_rows) {
+//   NW = 4 waves, <= 4 taps (<= 68 KB of LDS, two workgroups per CU): the sub-pixel phases of the transposed convs;
+//   NW = 8 waves, <= 9 taps (<= 157 KB, one workgroup per CU): 3x3 convolutions and their data gradients.
+// Taps tap0 .. tap0+ntaps-1 of the geometry.
+constexpr int WSTAT_TAPS4 = 4, WSTAT_TAPS8 = 9;
+template <int ACT, bool HAS_T, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kernel(
+    ConvGeom g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
+    float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps) {
+    constexpr int BMT = 32 * NW;                                   // rows per tile: 32 per wave
     extern __shared__ __align__(16) float wstat_smem[];
     float* Ws = wstat_smem;                                        // [ntaps][64][LDA]
-    int* opix = reinterpret_cast<int*>(Ws + g.ntaps * 64 * LDA);   // [2][4 waves][32 rows]
-    float* red = reinterpret_cast<float*>(opix + 2 * 4 * 32);      // [4][128]
+    int* opix = reinterpret_cast<int*>(Ws + ntaps * 64 * LDA);     // [2][NW waves][32 rows]
+    float* red = reinterpret_cast<float*>(opix + 2 * NW * 32);     // [NW][128]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int q = tid & 15, rb = tid >> 4;
     const int nb = blockIdx.y;
     {
-        const float* Wn = Wt + nb * g.w_nblk_stride + (long)rb * g.w_pitch + 4 * q;
-        const long w16 = 16L * g.w_pitch;
-        for (int t = 0; t < g.ntaps; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                *reinterpret_cast<float4*>(&Ws[(t * 64 + rb + 16 * e) * LDA + 4 * q]) =
-                    *reinterpret_cast<const float4*>(Wn + g.w_off[t] + e * w16);
+        const float* Wn = Wt + nb * g.w_nblk_stride + 4 * q;
+        for (int t = 0; t < ntaps; ++t)
+            for (int row = rb; row < 64; row += 4 * NW)
+                *reinterpret_cast<float4*>(&Ws[(t * 64 + row) * LDA + 4 * q]) =
+                    *reinterpret_cast<const float4*>(Wn + g.w_off[tap0 + t] + (long)row * g.w_pitch);
     }
     // BatchNorm fold of this lane's channels (8kk + 4h .. +3)
-    float4 sc[8], sh[8];
+    float4 sc[HAS_T ? 8 : 1], sh[HAS_T ? 8 : 1];
+    if (HAS_T) {
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        sc[kk] = *reinterpret_cast<const float4*>(a_scale + 8 * kk + 4 * h);
-        sh[kk] = *reinterpret_cast<const float4*>(a_shift + 8 * kk + 4 * h);
+        for (int kk = 0; kk < 8; ++kk) {
+            sc[kk] = *reinterpret_cast<const float4*>(a_scale + 8 * kk + 4 * h);
+            sh[kk] = *reinterpret_cast<const float4*>(a_shift + 8 * kk + 4 * h);
+        }
     }
-    const int ntiles = (g.rows_total + BM - 1) / BM;
-    const int nsteps = ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * g.ntaps;
+    const int ntiles = (g.rows_total + BMT - 1) / BMT;
+    const int nsteps = ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * ntaps;
     const RowDecoder dec(g);
     float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
     const float b0 = bias ? bias[nb * 64 + i] : 0.f;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_wstat_kernel(ConvGeom g, con
     bool ok_next = false;
     int ltile = blockIdx.x, par = 0;
     auto rows_of_tile = [&](int tile, int* op) {                   // op: this wave's 32 output pixels
-        const int r = tile * BM + 32 * w + i;                      // this lane's row
+        const int r = tile * BMT + 32 * w + i;                     // this lane's row
         int opx = -1;
         dec.decode<1>(r, 0, [&](int, int n, int y, int x) {
             ri = make_row(g, r, n, y, x);
@@ -501,9 +501,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_wstat_kernel(ConvGeom g, con
         });
         if (h == 0) op[i] = opx;
     };
-    auto load_frag = [&](int t) {                                  // raw loads: the fold is applied when consumed
-        const int dy = g.dy[t], dx = g.dx[t];
-        const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[t];
+    auto load_frag = [&](int t) {                                  // raw loads: fold / zeroing applied when consumed
+        const int dy = g.dy[tap0 + t], dx = g.dx[tap0 + t];
+        const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[tap0 + t];
         ok_next = ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
         const float* p = A + (ok_next ? ri.off + delta : 0) + 4 * h;
 #pragma unroll
@@ -518,13 +518,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_wstat_kernel(ConvGeom g, con
         {
             const bool ok = ok_next;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<true>(ra[kk], ok, sc[kk], sh[kk]);
+            for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<HAS_T>(ra[kk], ok, sc[HAS_T ? kk : 0], sh[HAS_T ? kk : 0]);
         }
         int tn = t + 1;
-        if (tn == g.ntaps) {
+        if (tn == ntaps) {
             tn = 0;
             ltile += gridDim.x;
-            rows_of_tile(ltile, opix + ((par ^ 1) * 4 + w) * 32);
+            rows_of_tile(ltile, opix + ((par ^ 1) * NW + w) * 32);
         }
         load_frag(tn);
         __builtin_amdgcn_sched_barrier(0);
@@ -552,15 +552,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_wstat_kernel(ConvGeom g, con
             p4 = pn; r4 = rn;
         }
         if (tn == 0) {
-            const int* op_w = opix + (par * 4 + w) * 32;
+            const int* op_w = opix + (par * NW + w) * 32;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int op = op_w[(reg & 3) + 8 * (reg >> 2) + 4 * h];
                 if (op >= 0) {
+                    float* o = out + (long)op * g.o_pitch + nb * 64;
                     const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
                     ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
                     ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
-                    float* o = out + (long)op * g.o_pitch + nb * 64;
                     o[i] = apply_act<ACT>(v0);
                     o[32 + i] = apply_act<ACT>(v1);
                 }
@@ -580,13 +580,53 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_wstat_kernel(ConvGeom g, con
         }
         __syncthreads();
         if (tid < 128) {
-            const float v = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) v += red[ww * 128 + tid];
             stats_part[(long)blockIdx.x * 128 + tid] = v;
             // the caller sized the partials for cmvae_conv_gemm_grid() workgroups: the rows this launch does not
-            // own (it runs fewer, two per CU) are zeroed
+            // own (it runs fewer, one or two per CU) are zeroed
             for (int r = blockIdx.x + gridDim.x; r < stats_rows; r += gridDim.x) stats_part[(long)r * 128 + tid] = 0.f;
         }
     }
+}
+
+template <int ACT, bool HAS_T, int NW>
+static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, const float* bias, const float* a_scale,
+                        const float* a_shift, float* out, float* stats_part, int stats_rows, int n_col_blocks,
+                        int tap0, int ntaps, hipStream_t st) {
+    const size_t lds = (size_t)ntaps * 64 * LDA * sizeof(float) + 2 * NW * 32 * sizeof(int) + NW * 128 * sizeof(float);
+    static const bool opted = [] {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        return true;
+    }();
+    (void)opted;
+    const int ntiles = (g.rows_total + 32 * NW - 1) / (32 * NW);
+    const int cap = NW == 4 ? 512 : 256;                           // resident workgroups
+    const dim3 grid(ntiles < cap ? ntiles : cap, n_col_blocks);
+    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias, a_scale,
+                       a_shift, out, stats_part, stats_rows, tap0, ntaps);
+    return check_launch("conv_gemm_wstat_kernel");
+}
+
+template <int ACT, bool HAS_T>
+static int dispatch_wstat(const ConvGeom& g, const float* A, const float* Wt, const float* bias, const float* a_scale,
+                          const float* a_shift, float* out, float* stats_part, int stats_rows, int n_col_blocks,
+                          hipStream_t st, bool* handled) {
+    *handled = true;
+    if (g.ntaps <= WSTAT_TAPS4)
+        return launch_wstat<ACT, HAS_T, 4>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, n_col_blocks, 0,
+                                           g.ntaps, st);
+    // 8 waves, one workgroup per CU: worth its 157 KB weight fill from a few tiles per workgroup on.  (Splitting a
+    // 16-tap data gradient into two accumulating 8-tap launches was measured: no gain, the read-modify-write of the
+    // output eats what the barriers cost.)
+    if (g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 200 * 256)
+        return launch_wstat<ACT, HAS_T, 8>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, n_col_blocks, 0,
+                                           g.ntaps, st);
+    *handled = false;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------- weight gradient
@@ -828,6 +868,21 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     if (g.rows_total == 0) return 0;
     dim3 grid(gemm_grid(g.rows_total, n_col_blocks), n_col_blocks);
     hipStream_t st = (hipStream_t)stream;
+    {   // weight-stationary, barrier-free kernel wherever the launch's weight tiles fit LDS
+        bool handled = false;
+        int e = 0;
+        const int srows = (int)grid.x;
+#define CMVAE_WSTAT(ACT)                                                                                              \
+        e = a_scale ? dispatch_wstat<ACT, true>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, srows, n_col_blocks, st, &handled) \
+                    : dispatch_wstat<ACT, false>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, srows, n_col_blocks, st, &handled)
+        switch (act) {
+            case 0: CMVAE_WSTAT(0); break;
+            case 1: CMVAE_WSTAT(1); break;
+            default: CMVAE_WSTAT(2); break;
+        }
+#undef CMVAE_WSTAT
+        if (handled || e) return e;
+    }
     if (!a_scale) {          // no folded BatchNorm: operand fragments straight from global memory
         switch (act) {
             case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
@@ -835,25 +890,6 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
             default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
         }
         return check_launch("conv_gemm_direct_kernel");
-    }
-    if (g.ntaps <= WSTAT_TAPS) {   // folded BatchNorm, few taps: weights stay in LDS for the whole launch
-        const size_t lds = (size_t)g.ntaps * 64 * LDA * sizeof(float) + 2 * 4 * 32 * sizeof(int) + 4 * 128 * sizeof(float);
-        static const bool opted = [] {
-            const int cap = WSTAT_TAPS * 64 * LDA * (int)sizeof(float) + 4096;
-            (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-            (void)hipGetLastError();
-            return true;
-        }();
-        (void)opted;
-        dim3 wgrid(grid.x < 512 ? grid.x : 512, n_col_blocks);     // two resident workgroups per CU
-        switch (act) {
-            case 0: hipLaunchKernelGGL((conv_gemm_wstat_kernel<0>), wgrid, dim3(256), lds, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part, (int)grid.x); break;
-            case 1: hipLaunchKernelGGL((conv_gemm_wstat_kernel<1>), wgrid, dim3(256), lds, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part, (int)grid.x); break;
-            default: hipLaunchKernelGGL((conv_gemm_wstat_kernel<2>), wgrid, dim3(256), lds, st, g, A, Wt, bias, a_scale, a_shift, out, stats_part, (int)grid.x); break;
-        }
-        return check_launch("conv_gemm_wstat_kernel");
     }
 #define CMVAE_LAUNCH_GEMM(ACT)                                                                                  \
     if (a_scale)                                                                                                \

@@ -86,8 +86,15 @@ def test_two_ranks_on_hip_kernels_equal_one_process(device):
     mean_losses = (out[0]['losses'] + out[1]['losses']) / 2
     assert torch.allclose(mean_losses, losses, rtol=2e-5, atol=1e-6), (mean_losses, losses)
     scale = float(grads.abs().max())
+    # Adam's first step is lr * g / (|g| + eps): where |g| is near eps = 1e-8 the update is rounding noise of the
+    # gradient, so the weights are compared where the gradient is well above that
+    gw = flat.views[[id(p) for p in flat.params].index(id(model.proj[0].weight))].detach().cpu()
+    solid = gw.abs() > 1e-5 * scale
+    assert float(solid.float().mean()) > 0.5
     for r in range(world):
         assert float((out[r]['grads'] - grads).abs().max()) < 2e-4 * scale
-        assert torch.allclose(out[r]['w'], model.proj[0].weight.detach().cpu(), atol=1e-5)
+        dw = (out[r]['w'] - model.proj[0].weight.detach().cpu()).abs()
+        assert float(dw[solid].max()) < 1e-5 and float(dw.max()) < 2.1e-3      # never more than two steps of lr
         assert torch.allclose(out[r]['rm'], model.decoder.decoder[1].running_mean.detach().cpu(), atol=1e-6)
     assert torch.equal(out[0]['grads'], out[1]['grads'])
+    assert torch.equal(out[0]['w'], out[1]['w'])                            # the ranks stay in lock step
