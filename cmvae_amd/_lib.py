@@ -55,6 +55,8 @@ SIGNATURES = {
     'cmvae_mixture_loglik_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_mixture_loglik_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'cmvae_center_rows_chunks': (c_int, [c_int]),
+    'cmvae_center_rows': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'cmvae_reparam_logq_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'cmvae_reparam_logq_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p]),

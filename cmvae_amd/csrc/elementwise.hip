@@ -156,9 +156,73 @@ __global__ __launch_bounds__(256) void expm_trace_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ centring of an episode's latents
+// out[b][n][:] = x[b][n][:] - mean_n x[b][n][:]   (omniglot/model.py:449: the bulk causal layer sees q_z minus its
+// per-episode mean).  Two launches: per-chunk column sums, then the subtraction (every workgroup re-reduces the
+// <= 64 chunk sums of its episode from L2 in a fixed order).  The map is a symmetric projection, so the backward
+// pass is the same call on the gradient.
+constexpr int CENTER_ROWS = 256;          // rows per chunk
+__global__ __launch_bounds__(256) void center_partial_kernel(const float* __restrict__ x, int N,
+                                                             float* __restrict__ part) {
+    __shared__ __align__(16) float red[16 * 64];
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
+    const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+    const float* xb = x + (size_t)b * N * 64;
+    const int r0 = chunk * CENTER_ROWS, r1 = min(N, r0 + CENTER_ROWS);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0 + rb; r < r1; r += 16) {
+        const float4 v = reinterpret_cast<const float4*>(xb + (size_t)r * 64)[q];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(&red[rb * 64 + 4 * q]) = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r * 64 + threadIdx.x];
+        part[((size_t)b * nchunk + chunk) * 64 + threadIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(256) void center_apply_kernel(const float* __restrict__ x, int N,
+                                                           const float* __restrict__ part, float* __restrict__ out) {
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
+    const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < nchunk; ++c) {
+        const float4 v = reinterpret_cast<const float4*>(part + ((size_t)b * nchunk + c) * 64)[q];
+        m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w;
+    }
+    const float inv = 1.f / (float)N;
+    m.x *= inv; m.y *= inv; m.z *= inv; m.w *= inv;
+    const float* xb = x + (size_t)b * N * 64;
+    float* ob = out + (size_t)b * N * 64;
+    const int r0 = chunk * CENTER_ROWS, r1 = min(N, r0 + CENTER_ROWS);
+    for (int r = r0 + rb; r < r1; r += 16) {
+        float4 v = reinterpret_cast<const float4*>(xb + (size_t)r * 64)[q];
+        v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
+        reinterpret_cast<float4*>(ob + (size_t)r * 64)[q] = v;
+    }
+}
+
 }  // namespace cmvae
 
 using namespace cmvae;
+
+extern "C" int cmvae_center_rows_chunks(int N) {
+    cmvae::clear_stale_error();
+    return (N + CENTER_ROWS - 1) / CENTER_ROWS;
+}
+
+extern "C" int cmvae_center_rows(const float* x, int B, int N, float* part, float* out, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(x && part && out, "cmvae_center_rows: NULL tensor");
+    CMVAE_REQUIRE(B >= 1 && B <= 65535 && N >= 1, "cmvae_center_rows: bad shape B=%d N=%d", B, N);
+    const dim3 grid((N + CENTER_ROWS - 1) / CENTER_ROWS, B);
+    hipLaunchKernelGGL(center_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, N, part);
+    if (int e = check_launch("center_partial_kernel")) return e;
+    hipLaunchKernelGGL(center_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, N, (const float*)part, out);
+    return check_launch("center_apply_kernel");
+}
 
 extern "C" int cmvae_reparam_logq_fwd(const float* mean, const float* logvar, const float* eps, int rows, int M,
                                       float* z, float* logq, void* stream) {

@@ -203,7 +203,7 @@ class OmniglotGMVAE(_GMVAEBase):
             eps = self._draw_eps(q_mean, M)
         q_z4, log_q_z = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
         q_z = q_z4.view(B, S * M, D)
-        q_eps = self.causal(q_z - q_z.mean(1, keepdim=True))
+        q_eps = self.causal(ops.center_rows(q_z))
         A = self.causal.get_w()
         # proj: the last Linear's rows are permuted so H_rec comes out channels-last ([2,2,64] per image)
         h = torch.cat([q_z, q_eps], -1).view(-1, 2 * D)

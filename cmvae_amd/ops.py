@@ -263,6 +263,32 @@ def mixture_loglik(z, mu, logw):
     return _MixtureLogLik.apply(z, mu.detach(), logw)
 
 
+def _center(x):
+    B, N, d = x.shape
+    if d != D:
+        raise RuntimeError('cmvae_amd: center_rows expects [B,N,64]')
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    part = torch.empty(B, lib.cmvae_center_rows_chunks(N), D, device=x.device)
+    check(lib.cmvae_center_rows(_p(x), B, N, _p(part), _p(out), _stream()), 'cmvae_center_rows')
+    return out
+
+
+class _CenterRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _center(_req(x, 'x'))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _center(g)
+
+
+def center_rows(x):
+    """x - x.mean(1, keepdim=True) for x [B,N,64] (omniglot/model.py:449)."""
+    return _CenterRows.apply(x)
+
+
 class _ReparamLogQ(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mean, logvar, eps):

@@ -115,6 +115,12 @@ int cmvae_mixture_loglik_bwd(const float* z, const float* mu, const float* logw,
                              int B, int N, int K, void* workspace, size_t workspace_bytes,
                              float* dz, float* dlogw, void* stream);
 
+/* q_z - q_z.mean(1, keepdim=True) (omniglot/model.py:449, the input of the bulk causal layer):
+ * x [B,N,64] -> out [B,N,64]; part [B][cmvae_center_rows_chunks(N)][64] is scratch.  The map is a symmetric
+ * projection: its backward is the same call on the gradient.                                     */
+int cmvae_center_rows_chunks(int N);
+int cmvae_center_rows(const float* x, int B, int N, float* part, float* out, void* stream);
+
 /* ---- reparametrisation + log q(z|x) (omniglot/model.py:111-122, 496-501)
  * z[r,m,:] = eps[r,m,:]*exp(0.5*logvar[r,:]) + mean[r,:] ; logq[r,m] = glp(z, mean, logvar)
  * rows = B*S, mean/logvar [rows,64], eps/z [rows,M,64], logq [rows,M] (may be NULL).

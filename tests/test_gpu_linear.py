@@ -136,3 +136,19 @@ def test_attention_rejects_bad_shapes():
     with pytest.raises(RuntimeError):
         q = torch.randn(1, 2000, 64).cuda()
         attention(q, q, q, 1, 0.1)
+
+
+@pytest.mark.parametrize('B,N', [(4, 9600), (3, 257), (2, 1), (1, 256)])
+def test_center_rows(B, N):
+    """q_z - q_z.mean(1, keepdim=True) (omniglot/model.py:449) and its gradient against torch."""
+    from cmvae_amd.ops import center_rows
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B, N, 64, generator=g) + 0.5
+    go = torch.randn(B, N, 64, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    yr = xr - xr.mean(1, keepdim=True)
+    yr.backward(go.double())
+    xd = x.cuda().requires_grad_(True)
+    yd = center_rows(xd)
+    yd.backward(go.cuda())
+    assert _rel(yd, yr) < 1e-6 and _rel(xd.grad, xr.grad) < 1e-6
