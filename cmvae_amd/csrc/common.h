@@ -41,7 +41,22 @@ inline int resident_blocks(const void* kernel, int block_threads, int fallback) 
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// expm1 accurate to ~2e-7 relative without the cost of ocml's expm1f.
+__device__ __forceinline__ float expm1_fast(float x) {
+    // Horner, degree 8 on [-0.35, 0]; exp(x)-1 below that (|result| >= 0.29)
+    float p = 1.f / 40320.f;
+    p = fmaf(p, x, 1.f / 5040.f);
+    p = fmaf(p, x, 1.f / 720.f);
+    p = fmaf(p, x, 1.f / 120.f);
+    p = fmaf(p, x, 1.f / 24.f);
+    p = fmaf(p, x, 1.f / 6.f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.f);
+    p = p * x;
+    float e = __expf(x) - 1.f;
+    return x > -0.35f ? p : e;
+}
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1_fast(x); }
 
 }  // namespace cmvae
 

@@ -128,7 +128,7 @@ __device__ __forceinline__ float4 transform_a(float4 v, bool ok, const float4& s
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {
     if (ACT == 1) return fmaxf(v, 0.f);
-    if (ACT == 2) return v > 0.f ? v : expm1f(v);
+    if (ACT == 2) return elu1(v);
     return v;
 }
 
