@@ -435,13 +435,13 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
             mx = fmaxf(mx, __shfl_xor(mx, 1));
             float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < KH; ++j) sum += expf(r[j] - mx);
+            for (int j = 0; j < KH; ++j) sum += __expf(r[j] - mx);     // hardware exp/log: 1e-4 tolerance on EM parameters
             sum += __shfl_xor(sum, 1);
-            const float lse = mx + logf(sum);
+            const float lse = mx + __logf(sum);
             if (a.lse && half == 0 && valid) a.lse[(size_t)b * N + row0 + erow] = lse;
             const float gs = valid ? gv : 0.f;
 #pragma unroll
-            for (int j = 0; j < KH; ++j) r[j] = expf(r[j] - lse) * gs;
+            for (int j = 0; j < KH; ++j) r[j] = __expf(r[j] - lse) * gs;
         }
 #pragma unroll
         for (int j = 0; j < KH; ++j) {
