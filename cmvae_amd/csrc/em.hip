@@ -771,9 +771,16 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(const float* __re
             const int k = w + 4 * j;
             float acc = 0.f;
 #pragma unroll 4
-            for (int d = 0; d < D; ++d) {
-                const float df = zr[d] - mus[k * D + d];
-                acc += lvs[k * D + d] + (df * df) / evs[k * D + d];
+            for (int d4 = 0; d4 < D / 4; ++d4) {   // b128 broadcast reads, the reference's division and summation order
+                const float4 m4 = *reinterpret_cast<const float4*>(&mus[k * D + 4 * d4]);
+                const float4 l4 = *reinterpret_cast<const float4*>(&lvs[k * D + 4 * d4]);
+                const float4 e4 = *reinterpret_cast<const float4*>(&evs[k * D + 4 * d4]);
+                const float d0 = zr[4 * d4] - m4.x, d1 = zr[4 * d4 + 1] - m4.y;
+                const float d2 = zr[4 * d4 + 2] - m4.z, d3 = zr[4 * d4 + 3] - m4.w;
+                acc += l4.x + (d0 * d0) / e4.x;
+                acc += l4.y + (d1 * d1) / e4.y;
+                acc += l4.z + (d2 * d2) / e4.z;
+                acc += l4.w + (d3 * d3) / e4.w;
             }
             lls[row * LD + k] = fmaf(-0.5f, acc, D * LOG_NORM) + lws[k];
         }
