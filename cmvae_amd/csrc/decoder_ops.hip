@@ -320,7 +320,7 @@ constexpr int SP = 80;                 // a3 staging pitch: A-fragment (pixel-ma
 // MODE 1: the apply pass -- recomputes dybn3 and writes dy3 = scale*(dybn3 - c1 - xhat*c2) straight away, so the
 //         masked gradient never makes a round trip through HBM (saves a 1.9 GB write and a 3.9 GB re-read).
 template <int MODE>
-__global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restrict__ y3,
+__global__ __launch_bounds__(256, 3) void dec_out_bwd_kernel(const float* __restrict__ y3,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ mean,
@@ -411,8 +411,10 @@ __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restric
             float4 vr[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) vr[j] = vv[j];
-            if (rbk + 4 < RB) fetch_rows(img, rbk + 4);
-            else if (more) fetch_rows(img + gridDim.x, w);
+            if (MODE == 1) {      // apply pass: next rows requested before this block's work (registers allow it)
+                if (rbk + 4 < RB) fetch_rows(img, rbk + 4);
+                else if (more) fetch_rows(img + gridDim.x, w);
+            }
             // ---- G = D . w4^T
             {
                 const int px = 16 * rbk + i;
@@ -462,6 +464,11 @@ __global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restric
                 s2.x = fmaf(o.x, (v.x - mu.x) * is.x, s2.x); s2.y = fmaf(o.y, (v.y - mu.y) * is.y, s2.y);
                 s2.z = fmaf(o.z, (v.z - mu.z) * is.z, s2.z); s2.w = fmaf(o.w, (v.w - mu.w) * is.w, s2.w);
                 *reinterpret_cast<float4*>(&aw[rr * SP + 4 * i]) = a;
+            }
+            if (MODE == 0) {      // sums pass: requested after the rows are consumed, hidden behind the dW4 MFMAs and
+                                  // the third resident workgroup this buys
+                if (rbk + 4 < RB) fetch_rows(img, rbk + 4);
+                else if (more) fetch_rows(img + gridDim.x, w);
             }
             // ---- dW4 += a3^T . D   (contraction over the 16 pixels: 4 k-steps of 4)
 #pragma unroll
