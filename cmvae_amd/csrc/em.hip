@@ -1033,11 +1033,18 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
     p.N = Nu; p.K = K; p.tiles_per_block = tpb; p.nblk = nblk;
     f.init = 0; f.part_N = w.part_N; f.part_S1 = w.part_S1; f.part_S2 = w.part_S2; f.nblk = nblk;
     f.minv = w.minv; f.minv_stride = (size_t)D * D; f.tau_new = gamma1;
-    p.side_out = w.minv; p.side_nmat = B * K; p.side_rows = (B * K + nblk - 1) / nblk;
+    // the Gram inverses ride in the pass launch as extra grid rows, unless that would exceed the grid's y limit
+    const int side_rows = (B * K + nblk - 1) / nblk;
+    const bool fuse_inverse = B + side_rows <= 65535;
+    if (fuse_inverse) { p.side_out = w.minv; p.side_nmat = B * K; p.side_rows = side_rows; }
     for (int it = 0; it < iters; ++it) {
-        // inverse from the incoming logvar and tau = gamma1 (omniglot/model.py:259-265)
-        // C^T of every (episode, component), then ONE launch for the Gram inverses and the E/M pass (independent)
+        // inverse from the incoming logvar and tau = gamma1 (omniglot/model.py:259-265): C^T of every (episode,
+        // component), then ONE launch for the Gram inverses and the E/M pass (they are independent of each other)
         if (int e = launch_causal_diag(logvar, gamma1, B * K, *c, w.minv, st)) return e;
+        if (!fuse_inverse) {
+            hipLaunchKernelGGL(gram_inverse_kernel, dim3(B * K), dim3(256), 0, st, w.minv);
+            if (int e = check_launch("gram_inverse_kernel")) return e;
+        }
         if (int e = launch_pass(p, B, st)) return e;
         hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
         if (int e = check_launch("em_finalize_kernel")) return e;
