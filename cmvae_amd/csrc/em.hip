@@ -502,9 +502,14 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
     }
     // ---- block partials
     __syncthreads();
-    float* red = zs;                                  // reuse the tile: needs 2*32*64 (+ 2*32*64) + 128*KP floats
+    // both scratch areas of the epilogue live in buffers that are dead by now, each checked against its size:
+    // the S1 (and S2) slabs in the tile buffer, the N_k scratch [128][KP] in the responsibility buffer
+    constexpr int RED_FLOATS = (MOM2 ? 4 : 2) * 32 * 64;
+    static_assert(RED_FLOATS <= TRP * ZS_LD, "S1/S2 slabs must fit the tile buffer");
+    static_assert(TRP * KP <= TRP * RL, "N_k scratch must fit the responsibility buffer");
+    float* red = zs;
+    float* rn = Rs;                                   // [128][KP]
     if (a.part_N) {
-        float* rn = red + 2 * 2 * 32 * 64;            // [128][KP]
 #pragma unroll
         for (int j = 0; j < KH; ++j) rn[erow * KP + half + 2 * j] = nk[j];
     }
@@ -531,7 +536,6 @@ __global__ __launch_bounds__(256, (KH <= 8 && !DZ) ? 3 : 2) void em_pass_kernel(
     if (a.part_N && tid < 32) {
         float s = 0.f;
         if (tid < KP) {
-            const float* rn = red + 2 * 2 * 32 * 64;
             for (int r2 = 0; r2 < TRP; ++r2) s += rn[r2 * KP + tid];
         }
         a.part_N[((size_t)b * a.nblk + blk) * 32 + tid] = s;
