@@ -1,51 +1,96 @@
 #!/usr/bin/env python
 """bench.py — CMVAE episodic hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config o20|o5|mi|ce_sweep]
 
-Workload (BASELINE.json metric "train episodes/sec + eval EM episodes/sec, Omniglot 20-way"):
-Omniglot 20-way training step — meta-batch of 4 episodes per GPU, sample-size 300, 32 MC samples,
-10 unsupervised EM iterations, conv VAE + NOTEARS-MLP causal layer, Adam(lr 1e-3, wd 5e-5) —
-i.e. the reference's `python main.py --way 20 --sample-size 300` step (omniglot/trainer.py:79-95).
-One "step" = forward + backward + gradient all-reduce + optimizer step over one synthetic
-meta-batch that is already resident in HBM.  Weak scaling: per-GPU work fixed.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (a fresh
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` child, started before anything touches the GPU)
+and relays rank 0's JSON line; under torch.distributed.run it is one rank of the job (one process per GPU, RCCL).
 
-Prints ONE JSON line on rank 0.
+Workloads (BASELINE.json; --config):
+  o20 (default, the metric's config)  Omniglot 20-way training step — 4 episodes per GPU, sample-size 300, 32 MC
+        samples, 10 unsupervised EM iterations, conv VAE + NOTEARS-MLP causal layer, Adam(lr 1e-3, wd 5e-5), i.e.
+        `python main.py --way 20 --sample-size 300` (omniglot/trainer.py:79-95) — plus GMVAE.prediction, 1-/5-shot;
+  o5    the same with --way 5 --sample-size 200 (configs[1]);
+  mi    Mini-ImageNet 5-way training step on synthetic SimCLR features: 16 episodes per GPU x 5 items x 256 MC,
+        linear causal layer, lr 1e-4 (mimgnet/main.py:28-45), plus prediction at 1-/5-shot (75 queries);
+  ce_sweep  CelebA 5-way evaluation sweep: NOTEARS-MLP causal layer, 4096 test episodes per shot in calls of 256
+        episodes (semi-supervised EM batched over the call); `value` is eval episodes/s there.
+One "step" = forward + backward + gradient all-reduce + optimizer step over one synthetic meta-batch that is already
+resident in HBM.  Weak scaling: per-GPU work fixed.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WAY, SAMPLE, MC, B_PER_GPU, EM_ITERS, QUERY = 20, 300, 32, 4, 10, 15
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
+EM_ITERS, QUERY = 10, 15
+WAY, SAMPLE, MC, B_PER_GPU = 20, 300, 32, 4        # the default (o20) shape, for the probes under tools/
+
+CONFIGS = {
+    'o20': dict(variant='omniglot', way=20, sample=300, mc=32, batch=4, lr=1e-3, consts=(0.1, 0.1, 1e-4),
+                workload='Omniglot 20-way train step: 4 episodes/GPU x sample-size 300 x 32 MC, 10 EM iters, conv VAE '
+                         '+ NOTEARS-MLP causal, Adam (configs[2]; the metric\'s config)'),
+    'o5': dict(variant='omniglot', way=5, sample=200, mc=32, batch=4, lr=1e-3, consts=(0.1, 0.1, 1e-4),
+               workload='Omniglot 5-way train step: 4 episodes/GPU x sample-size 200 x 32 MC, 10 EM iters, conv VAE + '
+                        'NOTEARS-MLP causal, Adam (configs[1])'),
+    'mi': dict(variant='feat', linear=True, way=5, sample=5, mc=256, batch=16, lr=1e-4, consts=(0.1, 0.1, 1e-3), feat=256,
+               workload='Mini-ImageNet 5-way train step on synthetic SimCLR features: 16 episodes/GPU x 5 items x 256 '
+                        'MC, MLP VAE + linear causal layer, Adam (configs[3])'),
+    'ce_sweep': dict(variant='feat', linear=False, way=5, sample=5, mc=256, batch=16, lr=1e-4, consts=(1.0, 1.0, 1e-4),
+                     feat=256, eval_only=True, sweep_call=256, sweep_episodes=4096,
+                     workload='CelebA 5-way evaluation sweep on synthetic SimCLR features: 4096 test episodes per shot '
+                              'in calls of 256 episodes, 75 queries x 256 MC, NOTEARS-MLP causal layer (configs[4])'),
+}
 
 
 def synth_images(n, s, device, seed):
+    import torch
     g = torch.Generator(device='cpu').manual_seed(seed)
     return (torch.rand(n, s, 1, 28, 28, generator=g) < 0.15).float().to(device)
 
 
-def build_model(device):
-    from cmvae_amd.model import OmniglotGMVAE
+def synth_features(n, s, f, device, seed):
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return torch.relu(torch.randn(n, s, f, generator=g)).to(device)       # SimCLR features are post-ReLU
+
+
+def synth_batch(cfg, n, s, device, seed):
+    if cfg['variant'] == 'omniglot':
+        return synth_images(n, s, device, seed)
+    return synth_features(n, s, cfg['feat'], device, seed)
+
+
+def model_kwargs(cfg):
+    return dict(unsupervised_em_iters=EM_ITERS, semisupervised_em_iters=EM_ITERS, fix_pi=False,
+                component_size=cfg['way'], latent_size=64, train_mc_sample_size=cfg['mc'],
+                test_mc_sample_size=cfg['mc'])
+
+
+def build_model(device, cfg=None):
+    import torch
+    from cmvae_amd.model import OmniglotGMVAE, FeatureGMVAE
+    cfg = cfg or CONFIGS['o20']
     torch.manual_seed(10086)
-    m = OmniglotGMVAE(input_shape=[1, 28, 28], unsupervised_em_iters=EM_ITERS, semisupervised_em_iters=EM_ITERS,
-                      fix_pi=False, hidden_size=64, component_size=WAY, latent_size=64,
-                      train_mc_sample_size=MC, test_mc_sample_size=MC)
+    if cfg['variant'] == 'omniglot':
+        m = OmniglotGMVAE(input_shape=[1, 28, 28], hidden_size=64, **model_kwargs(cfg))
+    else:
+        m = FeatureGMVAE(input_shape=cfg['feat'], linear=cfg['linear'], **model_kwargs(cfg))
     return m.to(device)
 
 
 def event_time_ms(fn, iters, stream):
     """Average duration of fn() measured with HIP events on the stream the kernels run on."""
+    import torch
     start = torch.cuda.Event(enable_timing=True)
     end = torch.cuda.Event(enable_timing=True)
     fn()
@@ -58,14 +103,13 @@ def event_time_ms(fn, iters, stream):
     return start.elapsed_time(end) / iters
 
 
-def roofline_em_pass(device):
-    """HBM-bound kernel of the EM loop: the fused E-step/M-step pass (em_pass_kernel), at the training shape
-    (Omniglot 20-way: latency-bound, 10 MB per launch) and at the evaluation-sweep shape of the feature models
-    (256 episodes x 75 queries x 256 MC samples, 5-way: 1.26 GB per launch).
+def roofline_em_pass(device, shapes):
+    """HBM-bound kernel of the EM loop: the fused E-step/M-step pass (em_pass_kernel).
     Algorithmic bytes per launch = B*(N*D*4 + K*(2D+2)*4)  (SURVEY.md §8d)."""
+    import torch
     from cmvae_amd import ops
     out = []
-    for tag, (B, N, K) in (('train O20', (B_PER_GPU, SAMPLE * MC, WAY)), ('eval sweep 5-way', (256, 75 * 256, 5))):
+    for tag, (B, N, K) in shapes:
         g = torch.Generator(device='cpu').manual_seed(1)
         z = torch.randn(B, N, 64, generator=g).to(device)
         mu = torch.randn(B, K, 64, generator=g).to(device)
@@ -103,7 +147,7 @@ def pmc_traffic(select):
     committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes over this same
     workload, gfx950 correction applied).  PMC counters cannot be read from inside this process."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
     if not files:
         return None, None
     ks = json.load(open(files[-1]))['kernels']
@@ -122,9 +166,10 @@ def pmc_traffic_conv_gemm():
 
 
 def roofline_conv_gemm(step_fn):
-    """Dominant kernel of the step: conv_gemm_kernel (fp32 MFMA gather-GEMM: all decoder / encoder convs and
-    their data gradients).  Every launch of one extra, untimed training step is bracketed by HIP events on
-    the launch stream; achieved = sum of algorithmic FLOPs / sum of launch durations."""
+    """Dominant kernel family of the Omniglot step: the fp32-MFMA gather-GEMM (all decoder / encoder convs and their
+    data gradients).  Every launch of one extra, untimed training step is bracketed by HIP events on the launch
+    stream; achieved = sum of algorithmic FLOPs / sum of launch durations."""
+    import torch
     from cmvae_amd import conv
     rec = []
     orig = conv.conv_gemm
@@ -149,8 +194,8 @@ def roofline_conv_gemm(step_fn):
     total_flops = sum(f for _, _, f in rec)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     traffic, src = pmc_traffic_conv_gemm()
-    return {'kernel': 'conv_gemm_wstat_kernel + conv_gemm_direct_kernel (conv / conv-transpose / data-gradient launches)', 'bound': 'mfma',
-            'achieved': round(achieved, 2),
+    return {'kernel': 'conv_gemm_wstat_kernel + conv_gemm_direct_kernel (conv / conv-transpose / data-gradient launches)',
+            'bound': 'mfma', 'achieved': round(achieved, 2),
             'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': src,
             'launches_per_step': len(rec), 'avg_launch_us': round(total_ms * 1e3 / len(rec), 1),
@@ -158,30 +203,128 @@ def roofline_conv_gemm(step_fn):
             'share_of_step_ms': round(total_ms, 2)}
 
 
-def cpu_baseline(threads):
-    """The CPU oracle (a restatement of the reference's PyTorch op sequence) on the same workload,
-    bounded to ONE training step of 4 episodes (about 10-30 s of CPU work)."""
-    from cmvae_amd.model import OmniglotGMVAE
-    from oracle.gmvae_oracle import OracleGMVAE, make_trainable, train_step
-    torch.set_num_threads(threads)
+def roofline_linear(step_fn):
+    """Dominant kernel family of the feature-model step: the nn.Linear forward launches (cmvae_linear_fwd ->
+    conv_gemm_direct_kernel<.., LINEAR = true>): proj, the SAB projections, the (mu, logvar) head, causal fc1.
+    Algorithmic FLOPs per launch = 2 * rows * in_features * out_features."""
+    import torch
+    from cmvae_amd import linear as lin
+    rec = []
+    orig = lin.linear_fwd
+
+    def timed(x2, weight, bias, act, out=None):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(x2, weight, bias, act, out)
+        e1.record()
+        rec.append((e0, e1, 2.0 * x2.shape[0] * x2.shape[1] * weight.shape[0]))
+        return r
+
+    lin.linear_fwd = timed
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        lin.linear_fwd = orig
+    total_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+    total_flops = sum(f for _, _, f in rec)
+    achieved = total_flops / (total_ms * 1e-3) / 1e12
+    traffic, src = pmc_traffic(lambda k: k.startswith(('conv_gemm_kernel', 'conv_gemm_direct_kernel')) and
+                               k.endswith('true>'))
+    return {'kernel': 'conv_gemm_direct_kernel<LINEAR> (nn.Linear forward launches)', 'bound': 'mfma',
+            'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+            'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': src, 'launches_per_step': len(rec),
+            'avg_launch_us': round(total_ms * 1e3 / len(rec), 1),
+            'algorithmic_gflop_per_launch': round(total_flops / len(rec) / 1e9, 3),
+            'share_of_step_ms': round(total_ms, 2)}
+
+
+# ----------------------------------------------------------------------------- CPU baseline (oracle, bounded sample)
+def _oracle(cfg, trainable):
+    import numpy as np
+    import torch
+    from cmvae_amd.model import OmniglotGMVAE, FeatureGMVAE
+    from oracle.gmvae_oracle import OracleGMVAE, make_trainable
     torch.manual_seed(10086)
     np.random.seed(10086)
-    m = OmniglotGMVAE(unsupervised_em_iters=EM_ITERS, semisupervised_em_iters=EM_ITERS, component_size=WAY,
-                      train_mc_sample_size=MC, test_mc_sample_size=MC)
-    P = make_trainable({k: v.detach().clone() for k, v in m.state_dict().items()})
-    oracle = OracleGMVAE(P, 'omniglot', unsupervised_em_iters=EM_ITERS, semisupervised_em_iters=EM_ITERS,
-                         component_size=WAY, train_mc_sample_size=MC, test_mc_sample_size=MC)
-    opt = torch.optim.Adam([p for p in P.values() if p.requires_grad], lr=1e-3, weight_decay=5e-5)
-    X = synth_images(B_PER_GPU, SAMPLE, 'cpu', 7)
-    # tiny warm-up (thread pool, allocator) on 1 episode of 20 items; not part of the sample
-    small = OracleGMVAE(P, 'omniglot', unsupervised_em_iters=1, component_size=WAY, train_mc_sample_size=2)
-    small.forward(X[:1, :24], 0.1, 0.1, 1e-4)
+    kw = model_kwargs(cfg)
+    if cfg['variant'] == 'omniglot':
+        m = OmniglotGMVAE(**kw)
+        okw = dict(input_shape=(1, 28, 28))
+    else:
+        m = FeatureGMVAE(input_shape=cfg['feat'], linear=cfg['linear'], **kw)
+        okw = dict(input_shape=cfg['feat'], linear=cfg['linear'])
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    if trainable:
+        P = make_trainable(P)
+    del kw['latent_size']
+    return OracleGMVAE(P, cfg['variant'], **okw, **kw), P
+
+
+def cpu_baseline_train(cfg, threads, timed_steps=3):
+    """The CPU oracle (a restatement of the reference's PyTorch op sequence) on the same training workload:
+    1 warm-up step + `timed_steps` timed steps of one meta-batch."""
+    import torch
+    from oracle.gmvae_oracle import train_step
+    torch.set_num_threads(threads)
+    oracle, P = _oracle(cfg, True)
+    opt = torch.optim.Adam([p for p in P.values() if p.requires_grad], lr=cfg['lr'], weight_decay=5e-5)
+    X = synth_batch(cfg, cfg['batch'], cfg['sample'], 'cpu', 7)
+    train_step(oracle, opt, X, *cfg['consts'])                       # warm-up: thread pool, allocator, oneDNN plans
     t0 = time.perf_counter()
-    train_step(oracle, opt, X, 0.1, 0.1, 1e-4)
-    dt = time.perf_counter() - t0
-    return {'value': round(B_PER_GPU / dt, 4), 'unit': 'train episodes/s', 'cores': threads, 'kind': 'port',
-            'sample': '1 training step (4 episodes) of the same Omniglot 20-way workload, oracle/gmvae_oracle.py',
-            'seconds': round(dt, 2)}
+    for _ in range(timed_steps):
+        train_step(oracle, opt, X, *cfg['consts'])
+    dt = (time.perf_counter() - t0) / timed_steps
+    return {'value': round(cfg['batch'] / dt, 4), 'unit': 'train episodes/s', 'cores': threads, 'kind': 'port',
+            'sample': '1 warm-up + %d timed training steps (%d episodes each) of the same workload, '
+                      'oracle/gmvae_oracle.py' % (timed_steps, cfg['batch']),
+            'seconds_per_step': round(dt, 2)}
+
+
+def cpu_baseline_eval(cfg, threads, shots=(1, 5), calls=3, batch=None):
+    """GMVAE.prediction on the CPU oracle: `calls` calls per shot of `batch` episodes."""
+    import torch
+    torch.set_num_threads(threads)
+    oracle, _ = _oracle(cfg, False)
+    oracle.training = False
+    B = batch or cfg['batch']
+    way = cfg['way']
+    out = {'unit': 'eval episodes/s', 'cores': threads, 'kind': 'port',
+           'sample': '%d prediction calls per shot, %d episodes per call, oracle/gmvae_oracle.py' % (calls, B)}
+    for shot in shots:
+        tr, te = way * shot, way * QUERY
+        X = synth_batch(cfg, B, tr + te, 'cpu', 200 + shot)
+        ytr = torch.arange(way).repeat_interleave(shot)[None].repeat(B, 1)
+        oracle.prediction(X[:, :tr], ytr, X[:, tr:])                  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            oracle.prediction(X[:, :tr], ytr, X[:, tr:])
+        dt = (time.perf_counter() - t0) / calls
+        out['%dshot' % shot] = round(B / dt, 4)
+        out['%dshot_seconds_per_call' % shot] = round(dt, 2)
+    return out
+
+
+# ----------------------------------------------------------------------------- self-launch
+def self_launch(args):
+    """--gpus N > 1 without a torchrun environment: start N ranks in a fresh child before this process touches the
+    GPU (never re-exec a process that has initialised it) and pass its output through."""
+    import torch
+    n_dev = torch.cuda.device_count()                       # does not initialise the GPU
+    if n_dev < args.gpus:
+        print('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, n_dev), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1) // 2)))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -189,46 +332,38 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='o20')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-calls', type=int, default=10)
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
     t_start = time.perf_counter()
     from cmvae_amd import dist as cdist
     rank, world = cdist.init_from_env()
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run' % args.gpus)
+        raise SystemExit('bench.py: --gpus %d but the job has %d ranks' % (args.gpus, world))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, device=device)
+        torch.distributed.all_reduce(t)                      # the ranks RCCL actually connects
+        ranks_seen = int(t.item())
 
-    model = build_model(device)
-    flat = cdist.FlatGrads(model.parameters())
+    way, S, M, Bl = cfg['way'], cfg['sample'], cfg['mc'], cfg['batch']
+    model = build_model(device, cfg)
+    flat = cdist.FlatGrads(model.parameters()).overlap_tail(model.tail_param_count())
     from cmvae_amd.linear import FlatAdam
-    opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)          # Adam as in omniglot/trainer.py:48-52
+    opt = FlatAdam(flat, lr=cfg['lr'], weight_decay=5e-5)          # Adam as in omniglot/trainer.py:48-52
     np.random.seed(10086)
-    torch.manual_seed(10086 + rank)
-
-    # synthetic meta-batches, resident in HBM before the timed region; each rank owns its shard
-    n_pool = 4
-    pool = [synth_images(B_PER_GPU * world, SAMPLE, 'cpu', 100 + i)[cdist.shard_slice(B_PER_GPU * world, rank, world)]
-            .to(device) for i in range(n_pool)]
-    h_lambda, h_c, a_lambda = 0.1, 0.1, 1e-4
-    N = SAMPLE * MC
-
-    seeds = cdist.SeedUploader((B_PER_GPU, WAY), device)
-
-    def step(i):
-        model.train()
-        flat.zero()
-        X = pool[i % n_pool]
-        idx = seeds.upload(cdist.draw_em_init(N, WAY, B_PER_GPU * world, rank, world))
-        _, rec, kl, h_aug, _ = model(X, h_lambda, h_c, a_lambda, init_idx=idx)
-        (rec + kl + h_aug).backward()
-        flat.allreduce()
-        opt.step()
-        return rec, kl, h_aug
+    torch.manual_seed(10086)                                       # every rank alike, as main.py seeds them
 
     def barrier():
         if world > 1:
@@ -238,77 +373,125 @@ def main():
         if rank == 0:
             print('[bench %7.1fs] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    for i in range(args.warmup):
-        step(i)
-        torch.cuda.synchronize()
-        note('warmup step %d done' % i)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(i)
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
-    losses = [float(x) for x in last]
-    note('timed region done: %.2f ms/step' % (dt / args.steps * 1e3))
-    ms_per_step = dt / args.steps * 1e3
-    train_eps = B_PER_GPU * world * args.steps / dt
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t)
+        return dt
 
-    # eval: GMVAE.prediction, 20-way, query 15; B=4 episodes per call (the reference's default batch size) and
-    # B=32 per call (same episodes, larger calls: what Trainer.eval uses with --eval-batch-size 32)
-    eval_rates, eval_rates_b32 = {}, {}
+    h_lambda, h_c, a_lambda = cfg['consts']
+    N = S * M
+    out = {'metric': 'train episodes/sec (whole node) + eval EM episodes/sec, Omniglot 20-way', 'n_gpus': world,
+           'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32', 'data': 'synthetic', 'rccl_ranks': ranks_seen,
+           'config': {'workload': cfg['workload'], 'name': args.config, 'global_batch_episodes': Bl * world,
+                      'parallelism': 'dp%d' % world}}
+    step = None
+    if not cfg.get('eval_only'):
+        # synthetic meta-batches, resident in HBM before the timed region; each rank owns its shard
+        n_pool = 4
+        pool = [synth_batch(cfg, Bl * world, S, 'cpu', 100 + i)[cdist.shard_slice(Bl * world, rank, world)].to(device)
+                for i in range(n_pool)]
+        seeds = cdist.SeedUploader((Bl, way), device)
+
+        def step(i):
+            model.train()
+            flat.zero()
+            X = pool[i % n_pool]
+            idx = seeds.upload(cdist.draw_em_init(N, way, Bl * world, rank, world))
+            eps = cdist.draw_eps(Bl * world, S, M, 64, device, rank, world) if world > 1 else None
+            _, rec, kl, h_aug, _ = model(X, h_lambda, h_c, a_lambda, eps=eps, init_idx=idx)
+            (rec + kl + h_aug).backward()
+            flat.allreduce()
+            opt.step()
+            return rec, kl, h_aug
+
+        for i in range(args.warmup):
+            step(i)
+            torch.cuda.synchronize()
+            note('warmup step %d done' % i)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = step(i)
+        barrier()
+        torch.cuda.synchronize()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        losses = [float(x) for x in last]
+        note('timed region done: %.2f ms/step' % (dt / args.steps * 1e3))
+        out.update(value=round(Bl * world * args.steps / dt, 3), unit='train episodes/s',
+                   ms_per_step=round(dt / args.steps * 1e3, 3),
+                   final_losses={'rec': losses[0], 'kl': losses[1], 'h_aug': losses[2]})
+
+    # eval: GMVAE.prediction, query 15; the reference's episodes per call and 32 per call (what Trainer.eval uses
+    # with --eval-batch-size 32); the sweep config runs 256 episodes per call over 4096 episodes
     model.eval()
-    for B_eval, rates in ((B_PER_GPU, eval_rates), (32, eval_rates_b32)):
+    eval_rates = {}
+    if cfg.get('eval_only'):
+        plans = [(cfg['sweep_call'], 'eval_episodes_per_s', max(1, cfg['sweep_episodes'] // cfg['sweep_call']))]
+    else:
+        plans = [(Bl, 'eval_episodes_per_s', args.eval_calls), (32, 'eval_episodes_per_s_batch32', args.eval_calls)]
+    for B_eval, key, calls in plans:
+        rates = {}
         for shot in (1, 5):
-            tr, te = WAY * shot, WAY * QUERY
-            Xtr = synth_images(B_eval, tr, device, 200 + shot)
-            Xte = synth_images(B_eval, te, device, 300 + shot)
-            ytr = torch.arange(WAY, device=device).repeat_interleave(shot)[None].repeat(B_eval, 1)
+            if calls <= 0:
+                continue
+            tr, te = way * shot, way * QUERY
+            X = synth_batch(cfg, B_eval, tr + te, device, 200 + shot)
+            Xtr, Xte = X[:, :tr].contiguous(), X[:, tr:].contiguous()
+            ytr = torch.arange(way, device=device).repeat_interleave(shot)[None].repeat(B_eval, 1)
             for _ in range(2):
                 model.prediction(Xtr, ytr, Xte)
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(args.eval_calls):
-                y = model.prediction(Xtr, ytr, Xte)
+            for _ in range(calls):
+                model.prediction(Xtr, ytr, Xte)
             barrier()
             torch.cuda.synchronize()
-            edt = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([edt], device=device, dtype=torch.float64)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                edt = float(t)
-            rates['%dshot' % shot] = round(B_eval * world * args.eval_calls / edt, 2)
+            edt = max_over_ranks(time.perf_counter() - t0)
+            rates['%dshot' % shot] = round(B_eval * world * calls / edt, 2)
             note('eval B=%d %d-shot done' % (B_eval, shot))
+            del X, Xtr, Xte
+        eval_rates[key] = rates
+    out.update(eval_rates)
+    if cfg.get('eval_only'):
+        r = eval_rates['eval_episodes_per_s']
+        calls = plans[0][2]
+        out.update(value=r.get('5shot'), unit='eval episodes/s (5-shot)', steps=calls,
+                   ms_per_step=round(cfg['sweep_call'] * world / r['5shot'] * 1e3, 3) if r.get('5shot') else None)
 
-    # roofline of the dominant kernel: one extra, untimed, instrumented training step (all ranks take part:
-    # the step contains the BatchNorm-statistics and gradient all-reduces)
-    roof = roofline_conv_gemm(lambda: step(0))
+    # roofline of the dominant kernel: one extra, untimed, instrumented training step (all ranks take part: the step
+    # contains the BatchNorm-statistics and gradient all-reduces); the sweep config reports the EM pass
+    if step is not None:
+        roof = roofline_conv_gemm(lambda: step(0)) if cfg['variant'] == 'omniglot' else roofline_linear(lambda: step(0))
+    else:
+        roof = None
     if rank == 0:
-        out = {
-            'metric': 'train episodes/sec (whole node) + eval EM episodes/sec, Omniglot 20-way',
-            'value': round(train_eps, 3), 'unit': 'train episodes/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'Omniglot 20-way train step: 4 episodes/GPU x sample-size 300 x 32 MC, '
-                                   '10 EM iters, conv VAE + NOTEARS-MLP causal, Adam (configs[2]; the metric\'s config)',
-                       'global_batch_episodes': B_PER_GPU * world, 'parallelism': 'dp%d' % world},
-            'eval_episodes_per_s': eval_rates, 'eval_episodes_per_s_batch32': eval_rates_b32,
-            'final_losses': {'rec': losses[0], 'kl': losses[1], 'h_aug': losses[2]},
-        }
+        em_shapes = [('train %s' % args.config, (Bl, N, way))]
+        if args.config in ('o20', 'ce_sweep', 'mi'):
+            em_shapes.append(('eval sweep 5-way', (256, 75 * 256, 5)))
+        em_roof = roofline_em_pass(device, em_shapes)
+        if roof is None:
+            roof = em_roof[-1]
+            em_roof = em_roof[:-1]
         out['roofline'] = roof
-        out['roofline_other'] = roofline_em_pass(device)
+        out['roofline_other'] = em_roof
         note('roofline measurements done; starting cpu baseline')
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '16')))
-            cb = cpu_baseline(threads)
-            out['cpu_baseline'] = cb
-            out['speedup_vs_cpu'] = round(train_eps / cb['value'], 1)
+            if cfg.get('eval_only'):
+                cb = cpu_baseline_eval(cfg, threads, calls=2, batch=4)
+                out['cpu_baseline'] = dict(cb, value=cb['5shot'])
+                out['speedup_vs_cpu'] = round(out['value'] / cb['5shot'], 1)
+            else:
+                cb = cpu_baseline_train(cfg, threads)
+                out['cpu_baseline'] = cb
+                out['speedup_vs_cpu'] = round(out['value'] / cb['value'], 1)
+                note('cpu train baseline done; starting cpu eval baseline')
+                out['cpu_baseline_eval'] = cpu_baseline_eval(cfg, threads)
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:

@@ -596,7 +596,11 @@ __global__ __launch_bounds__(1024) void em_finalize_kernel(FinArgs a) {
 
     if (a.init && !a.semi) {
         // mean0 = z[idx] (then shrunk below)
-        if (tid < D) ms[tid] = a.z[((size_t)b * a.N + a.init_idx[b * K + k]) * D + tid];
+        // a seed outside [0, N) must never become an out-of-bounds read: it is clamped here; the host side validates
+        // indices that originate on the CPU and, with CMVAE_CHECK_INDICES=1, device tensors too (cmvae_amd/ops.py)
+        int64_t ix = a.init_idx[b * K + k];
+        ix = ix < 0 ? 0 : (ix >= a.N ? (int64_t)a.N - 1 : ix);
+        if (tid < D) ms[tid] = a.z[((size_t)b * a.N + (size_t)ix) * D + tid];
     } else if (a.init && a.semi) {
         if (tid < D) ms[tid] = sup1 / supN;
     } else {
@@ -821,16 +825,21 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(const float* __re
 // instantiations for K > 16 and the dz variant hold 2 per CU, their second round is a short one): a single
 // workgroup per CU would serialise its own load -> E-step -> M-step phases with nothing to overlap them.
 static int pick_tiles_per_block(int B, int N, int K, bool dz = false) {
-    const int tiles_ep = (N + TRP - 1) / TRP;
+    // degenerate shapes (no episode, no latent) reach this through the *_workspace_bytes queries, which cannot
+    // report an error: they are sized as one tile of one episode, the entry points reject them before any launch
+    if (B < 1) B = 1;
+    int tiles_ep = (N + TRP - 1) / TRP;
+    if (tiles_ep < 1) tiles_ep = 1;
     const int resident = (K <= 16 && !dz) ? 768 : 512;
     int nblk = resident / B;                             // workgroups per episode: at most one resident round
-    if (nblk < 1) nblk = 1;
     if (nblk > tiles_ep) nblk = tiles_ep;
     if (nblk < 1) nblk = 1;
-    return (tiles_ep + nblk - 1) / nblk;
+    return (tiles_ep + nblk - 1) / nblk;                 // >= 1
 }
 static int nblk_for(int N, int tpb) {
-    const int tiles_ep = (N + TRP - 1) / TRP;
+    int tiles_ep = (N + TRP - 1) / TRP;
+    if (tiles_ep < 1) tiles_ep = 1;
+    if (tpb < 1) tpb = 1;
     return (tiles_ep + tpb - 1) / tpb;
 }
 
@@ -943,19 +952,10 @@ extern "C" size_t cmvae_unsup_prior_workspace_bytes(int B, int N, int K) {
     return carve(nullptr, B, N, 0, K, false).bytes;
 }
 
-extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int64_t* init_idx, const cmvae_causal* c,
-                                 int iters, int fix_pi, float gamma1, void* workspace, size_t workspace_bytes,
-                                 float* pi, float* mu, float* tau, float* logw, void* stream) {
-    cmvae::clear_stale_error();
-    if (int e = check_causal(c)) return e;
-    CMVAE_REQUIRE(z && init_idx && pi && mu && tau && logw, "cmvae_unsup_prior: NULL tensor");
-    CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX && iters >= 0, "cmvae_unsup_prior: bad shape B=%d N=%d K=%d",
-                  B, N, K);
-    CMVAE_REQUIRE(K <= N, "cmvae_unsup_prior: K=%d > N=%d", K, N);
-    EmWorkspace w = carve(workspace, B, N, 0, K, false);
-    CMVAE_REQUIRE(workspace && workspace_bytes >= w.bytes, "cmvae_unsup_prior: workspace %zu < %zu", workspace_bytes,
-                  w.bytes);
-    hipStream_t st = (hipStream_t)stream;
+// the loop of cmvae_unsup_prior over a carved workspace (shared with the entry point that allocates nothing)
+static int unsup_prior_run(const float* z, int B, int N, int K, const int64_t* init_idx, const cmvae_causal* c,
+                           int iters, int fix_pi, float gamma1, const EmWorkspace& w, float* pi, float* mu,
+                           float* tau, float* logw, hipStream_t st) {
     const int tpb = pick_tiles_per_block(B, N, K), nblk = nblk_for(N, tpb);
     // initial inverse (tau0 = 1) and the loop inverse (tau = gamma1); both data independent
     if (int e = launch_gram_inverse(nullptr, 1.0f, 1, *c, w.minv0, st)) return e;
@@ -981,6 +981,27 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
         if (int e = check_launch("em_finalize_kernel")) return e;
     }
     return 0;
+}
+
+static int unsup_prior_check(const float* z, int B, int N, int K, const int64_t* init_idx, const cmvae_causal* c,
+                             int iters, float* pi, float* mu, float* tau, float* logw) {
+    if (int e = check_causal(c)) return e;
+    CMVAE_REQUIRE(z && init_idx && pi && mu && tau && logw, "cmvae_unsup_prior: NULL tensor");
+    CMVAE_REQUIRE(B > 0 && N > 0 && K >= 1 && K <= CMVAE_KMAX && iters >= 0, "cmvae_unsup_prior: bad shape B=%d N=%d K=%d",
+                  B, N, K);
+    CMVAE_REQUIRE(K <= N, "cmvae_unsup_prior: K=%d > N=%d", K, N);
+    return 0;
+}
+
+extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int64_t* init_idx, const cmvae_causal* c,
+                                 int iters, int fix_pi, float gamma1, void* workspace, size_t workspace_bytes,
+                                 float* pi, float* mu, float* tau, float* logw, void* stream) {
+    cmvae::clear_stale_error();
+    if (int e = unsup_prior_check(z, B, N, K, init_idx, c, iters, pi, mu, tau, logw)) return e;
+    EmWorkspace w = carve(workspace, B, N, 0, K, false);
+    CMVAE_REQUIRE(workspace && workspace_bytes >= w.bytes, "cmvae_unsup_prior: workspace %zu < %zu", workspace_bytes,
+                  w.bytes);
+    return unsup_prior_run(z, B, N, K, init_idx, c, iters, fix_pi, gamma1, w, pi, mu, tau, logw, (hipStream_t)stream);
 }
 
 extern "C" int cmvae_em_pass(const float* z, const float* mu, const float* logw, int B, int N, int K, void* workspace,

@@ -18,6 +18,7 @@ from ._lib import lib, check
 
 _p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 _LAYERS = ((4, 2), (3, 4), (4, 7))          # (kernel, input size) of the three 64->64 transposed convs
+TAPS = None                                 # tests set this to a dict: receives the activations and folds of a forward
 
 
 def _stream():
@@ -34,7 +35,12 @@ def bn_finalize(sums, count, bn, training_update=True):
     dev = sums.device
     scale, shift, mean, invstd = (torch.empty(64, device=dev) for _ in range(4))
     upd = training_update and bn.track_running_stats
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    if bn.momentum is None:
+        # nn.BatchNorm2d: cumulative moving average, 1 / num_batches_tracked counted after the increment (one
+        # host read of the counter; the reference's layers all use the default momentum 0.1)
+        mom = 1.0 / float(int(bn.num_batches_tracked) + 1) if upd else 0.0
+    else:
+        mom = bn.momentum
     check(lib.cmvae_bn_finalize(_p(sums), float(count), _p(bn.weight.detach()), _p(bn.bias.detach()), bn.eps, mom,
                                 _p(bn.running_mean) if upd else None, _p(bn.running_var) if upd else None,
                                 _p(scale), _p(shift), _p(mean), _p(invstd), _stream()), 'cmvae_bn_finalize')
@@ -50,12 +56,7 @@ def bn_eval_fold(bn):
     return scale, shift, bn.running_mean, invstd
 
 
-def _global_sums(sums):
-    if _dist.world_size() > 1:
-        g = sums.clone()
-        torch.distributed.all_reduce(g)
-        return g
-    return sums
+_global_sums = _dist.global_sums          # collective C2 (cmvae_amd/dist.py)
 
 
 def bn_bwd_finalize(sums_local, count):
@@ -130,6 +131,8 @@ class _DecoderBCE(torch.autograd.Function):
         ctx.M = M
         ctx.n = n
         ctx.acts, ctx.folds = acts, folds
+        if TAPS is not None:
+            TAPS['dec'] = (acts, folds)
         ctx.save_for_backward(p, tgt, w1, w2, w3, w4f)
         ctx.mark_non_differentiable(p)
         ctx.set_materialize_grads(False)

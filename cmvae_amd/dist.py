@@ -3,8 +3,9 @@
 
 The reference has no distributed code; this module is new work.  Two exchange steps exist:
   C1  one all-reduce of a flat fp32 gradient buffer per step (FlatGrads.allreduce);
-  C2  per-channel BatchNorm statistics (sync_batch_norm), Omniglot training only, so that
-      normalisation spans the whole meta-batch exactly as in the single-process reference.
+  C2  per-channel BatchNorm statistics (global_sums, called from the HIP encoder / decoder pipelines between
+      the GEMM-epilogue partial sums and cmvae_bn_finalize / cmvae_bn_bwd_finalize), Omniglot training only,
+      so that normalisation spans the whole meta-batch exactly as in the single-process reference.
 Everything else on the path is per-episode and needs no collective.
 """
 import os
@@ -59,6 +60,16 @@ def draw_em_init(n_samples, k, b_global, r=None, ws=None):
     return idx[shard_slice(b_global, r, ws)].astype(np.int64)
 
 
+def draw_eps(b_global, s, m, d, device, r=None, ws=None, dtype=torch.float32, generator=None):
+    """Reparametrisation noise of the global meta-batch, drawn exactly as a single process would — one
+    ``randn`` of shape [B_global, S, M, D] from the device generator (omniglot/model.py:121) — on every rank,
+    which keeps its own slice.  All ranks are seeded alike (main.py seeds 10086 everywhere), so the shards get
+    independent noise and the union equals the single-process draw.  Costs one extra 78 MB write per step at 8
+    ranks of the Omniglot 20-way shape."""
+    eps = torch.randn(b_global, s, m, d, device=device, dtype=dtype, generator=generator)
+    return eps[shard_slice(b_global, r, ws)]
+
+
 class SeedUploader:
     """EM seeds host -> device without stalling the host: a ring of pinned buffers and asynchronous copies.
     (A plain `.to(device)` from pageable memory blocks the host until everything queued before it has run, which
@@ -94,13 +105,30 @@ def gather_episode_values(values, local_batch):
     return torch.stack([p.view(-1, local_batch) for p in parts], 1).reshape(-1)
 
 
+def global_sums(sums):
+    """Collective C2: per-channel sums of a BatchNorm layer ({sum x, sum x^2} in the forward pass, {sum dy,
+    sum dy*xhat} in the backward pass; 128 floats) summed over the ranks.  The one implementation of the exchange:
+    the HIP pipelines (cmvae_amd/encoder.py, decoder.py) and the CPU restatement the gloo tests run
+    (tests/sync_bn_reference.py) both call it."""
+    if world_size() > 1:
+        g = sums.clone()
+        tdist.all_reduce(g, op=tdist.ReduceOp.SUM)
+        return g
+    return sums
+
+
 class FlatGrads:
-    """All parameter gradients in one flat fp32 buffer (4.56 MB for Omniglot): the step's gradient exchange is a
-    single all-reduce and the optimizer a single kernel over it.
+    """All parameter gradients in one flat fp32 buffer (4.56 MB for Omniglot): the step's gradient exchange is one
+    all-reduce per bucket and the optimizer a single kernel over it.
 
     Between `zero()` and `pack()` the parameters carry no `.grad`, so autograd hands every gradient over as it
     is produced (no per-parameter accumulation kernel); `pack()` — called by `allreduce()` — gathers them into
-    the flat buffer with one multi-tensor copy and points every `.grad` at its slice."""
+    the flat buffer with one multi-tensor copy and points every `.grad` at its slice.
+
+    `overlap_tail(n)`: the last n parameters (module order: ..., proj, decoder — the part of the model whose
+    backward runs first) form a second bucket whose all-reduce is issued from a gradient hook as soon as its last
+    gradient exists, so it travels over xGMI while the rest of the backward pass (causal layer, set attention,
+    encoder) still runs; `allreduce()` then exchanges the head bucket and waits for the tail."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -113,14 +141,42 @@ class FlatGrads:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
             p.grad = self.views[-1]
+        self._tail_start = len(self.params)      # index of the first parameter of the tail bucket
+        self._tail_off = self.flat.numel()
+        self._tail_pending = 0
+        self._tail_work = None
+        self._tail_done = False
+        self._hooks = []
+
+    def overlap_tail(self, n_tail_params):
+        """Make the last `n_tail_params` parameters a bucket that is all-reduced during the backward pass."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        n_tail_params = max(0, min(int(n_tail_params), len(self.params)))
+        self._tail_start = len(self.params) - n_tail_params
+        self._tail_off = sum(p.numel() for p in self.params[:self._tail_start]) if n_tail_params else self.flat.numel()
+        if n_tail_params and world_size() > 1:
+            for p in self.params[self._tail_start:]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._tail_hook))
+        return self
+
+    def _tail_hook(self, _param):
+        self._tail_pending -= 1
+        if self._tail_pending == 0 and not self._tail_done:
+            self._pack(self._tail_start, len(self.params))
+            self._tail_work = tdist.all_reduce(self.flat[self._tail_off:], op=tdist.ReduceOp.SUM, async_op=True)
+            self._tail_done = True
 
     def zero(self):
         for p in self.params:
             p.grad = None
+        self._tail_pending = len(self.params) - self._tail_start
+        self._tail_work, self._tail_done = None, False
 
-    def pack(self):
+    def _pack(self, lo, hi):
         src, dst = [], []
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             if p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
@@ -130,67 +186,22 @@ class FlatGrads:
         if dst:
             torch._foreach_copy_(dst, src)
 
+    def pack(self):
+        self._pack(0, len(self.params))
+
     def allreduce(self):
         """Gather the gradients, then mean over ranks (every loss term is a mean over equal-sized shards)."""
-        self.pack()
         ws = world_size()
-        if ws > 1:
+        if ws == 1:
+            self.pack()
+            return
+        if self._tail_done:
+            self._pack(0, self._tail_start)
+            tdist.all_reduce(self.flat[:self._tail_off], op=tdist.ReduceOp.SUM)
+            self._tail_work.wait()               # stream-ordered on RCCL: the host does not block
+            self._tail_work = None
+        else:
+            # no hook fired (overlap off, or a parameter of the tail got no gradient): one exchange of everything
+            self.pack()
             tdist.all_reduce(self.flat, op=tdist.ReduceOp.SUM)
-            self.flat.div_(ws)
-
-
-class _SyncBN(torch.autograd.Function):
-    """The C2 exchange step written out on torch tensors: what is summed, what is all-reduced and how the
-    backward uses the global sums.  The world_size-2 gloo tests run it on the CPU; on the GPU the same
-    exchange is `cmvae_amd.decoder._global_sums` between the HIP kernels (GEMM-epilogue partial sums ->
-    all-reduce -> cmvae_bn_finalize / cmvae_bn_bwd_finalize)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, eps):
-        C = x.shape[1]
-        red = [0, 2, 3]
-        stats = torch.empty(2 * C + 1, dtype=x.dtype, device=x.device)
-        stats[:C] = x.sum(red)
-        stats[C:2 * C] = (x * x).sum(red)
-        stats[2 * C] = x.numel() // C
-        if world_size() > 1:
-            tdist.all_reduce(stats, op=tdist.ReduceOp.SUM)
-        n = stats[2 * C]
-        mean = stats[:C] / n
-        var = stats[C:2 * C] / n - mean * mean
-        invstd = torch.rsqrt(var + eps)
-        xhat = (x - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
-        ctx.save_for_backward(xhat, weight, invstd, n)
-        ctx.mark_non_differentiable(mean, var, n)
-        return xhat * weight.view(1, C, 1, 1) + bias.view(1, C, 1, 1), mean, var, n
-
-    @staticmethod
-    def backward(ctx, dy, _gm, _gv, _gn):
-        xhat, weight, invstd, n = ctx.saved_tensors
-        C = dy.shape[1]
-        red = [0, 2, 3]
-        local = torch.empty(2 * C, dtype=dy.dtype, device=dy.device)
-        local[:C] = dy.sum(red)
-        local[C:] = (dy * xhat).sum(red)
-        dbias, dweight = local[:C].clone(), local[C:].clone()
-        if world_size() > 1:
-            tdist.all_reduce(local, op=tdist.ReduceOp.SUM)
-        mdy = (local[:C] / n).view(1, C, 1, 1)
-        mdyx = (local[C:] / n).view(1, C, 1, 1)
-        dx = (weight * invstd).view(1, C, 1, 1) * (dy - mdy - xhat * mdyx)
-        return dx, dweight, dbias, None
-
-
-def sync_batch_norm(x, bn):
-    """Training-mode BatchNorm2d with statistics all-reduced over ranks; running statistics are
-    updated like nn.BatchNorm2d (momentum, unbiased variance over the global count)."""
-    y, mean, var, n = _SyncBN.apply(x, bn.weight, bn.bias, bn.eps)
-    if bn.track_running_stats:
-        with torch.no_grad():
-            m = bn.momentum
-            bn.num_batches_tracked += 1
-            if m is None:
-                m = 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(var * (n / (n - 1)), alpha=m)
-    return y
+        self.flat.div_(ws)

@@ -26,6 +26,7 @@ def _need(t, name):
 
 
 _ws = {}
+TAPS = None          # tests set this to a dict: receives the output of every Linear+ReLU of a forward, in call order
 
 
 def _workspace(nbytes, device):
@@ -73,6 +74,8 @@ class _Linear(torch.autograd.Function):
             x2 = x2.contiguous()
         w = weight.contiguous()
         y = linear_fwd(x2, w, None if bias is None else bias.contiguous(), act)
+        if TAPS is not None and act == 1:
+            TAPS.setdefault('linear_relu', []).append(y)
         ctx.act, ctx.shape, ctx.has_bias = act, x.shape, bias is not None
         ctx.save_for_backward(x2, w, y if act else None)
         return y.view(*x.shape[:-1], w.shape[0])

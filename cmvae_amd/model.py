@@ -9,8 +9,8 @@ Where the arithmetic runs:
   * conv / conv-transpose / BatchNorm / max-pool / BCE (cmvae_amd/encoder.py, decoder.py), every
     nn.Linear (+ELU/ReLU), the bulk causal layer and Adam (cmvae_amd/linear.py): hand-written HIP
     kernels on the fp32-MFMA gather-GEMM family.
-  * Still ATen on the GPU: the 4-head softmax attention core inside the two SABs and the scalar
-    loss arithmetic.
+  * the 4-head softmax attention core of the two SABs: MFMA kernels (cmvae_amd/csrc/attention.hip).
+  * Still ATen on the GPU: tensor plumbing (cat, index gathers) and the scalar loss arithmetic.
 There is no CPU path: tensors must live on the GPU and the HIP library must be loadable.
 """
 import math
@@ -51,6 +51,14 @@ class _GMVAEBase(nn.Module):
             self.register_buffer('log_2', torch.tensor(np.log(2)))
         self.register_buffer('uniform_pi', torch.ones(self.component_size) / self.component_size)
 
+    def tail_param_count(self):
+        """Number of trailing parameters (module order) whose gradients are complete first in the backward pass —
+        proj and, for Omniglot, the decoder: the bucket `dist.FlatGrads.overlap_tail` sends early."""
+        n = len(list(self.proj.parameters()))
+        if hasattr(self, 'decoder'):
+            n += len(list(self.decoder.parameters()))
+        return n
+
     # ------------------------------------------------------------------ small pieces
     def _causal_desc(self):
         c = self.causal
@@ -84,19 +92,34 @@ class _GMVAEBase(nn.Module):
         return linear(H, self.q_z_given_H[2].weight, self.q_z_given_H[2].bias)
 
     def get_unsupervised_prior(self, z, init_idx=None):
-        """(pi_k, mu_k, trace_k) after `unsupervised_em_iters` EM iterations; also returns logw."""
+        """(pi_k, mu_k, trace_k) after `unsupervised_em_iters` EM iterations, detached, as a generator like the
+        reference's (omniglot/model.py:367)."""
+        return (p for p in self._unsup_prior(z, init_idx)[:3])
+
+    def get_semisupervised_prior(self, unsupervised_z, supervised_z, y):
+        """(pi_k, mu_k, logvar_k, trace_k), detached (omniglot/model.py:370-412).  y: int64 labels [B,Ns] or the
+        reference's one-hot float [B,Ns,K]."""
+        return (p for p in self._semi_prior(unsupervised_z, supervised_z, y)[:4])
+
+    def _unsup_prior(self, z, init_idx=None):
+        """(pi_k, mu_k, trace_k, logw): the prior plus the E-step log-weights the kernels hand on."""
         if init_idx is None:
             init_idx = self._draw_init_idx(z.shape[0], z.shape[1], z.device)
-        elif not isinstance(init_idx, torch.Tensor):
-            init_idx = torch.as_tensor(np.asarray(init_idx), dtype=torch.int64).to(z.device)
+        elif not isinstance(init_idx, torch.Tensor) or not init_idx.is_cuda:
+            host = np.asarray(init_idx.numpy() if isinstance(init_idx, torch.Tensor) else init_idx)
+            ops.check_index_range(host, z.shape[1], 'init_idx')      # host-side indices: checked before upload
+            init_idx = torch.as_tensor(host, dtype=torch.int64).to(z.device)
         with torch.no_grad():
             return ops.unsup_prior(z.detach().contiguous(), init_idx.contiguous(), self._causal_desc(),
                                    self.unsupervised_em_iters, self.fix_pi, self.gamma1)
 
-    def get_semisupervised_prior(self, unsupervised_z, supervised_z, y):
-        """y: int64 labels [B,Ns] (or the reference's one-hot float [B,Ns,K])."""
+    def _semi_prior(self, unsupervised_z, supervised_z, y):
+        """(pi_k, mu_k, logvar_k, trace_k, logw)."""
         if y.dim() == 3:
             y = y.argmax(-1)
+        if not y.is_cuda:
+            ops.check_index_range(y, self.component_size, 'y (support labels)')
+            y = y.to(unsupervised_z.device)
         with torch.no_grad():
             return ops.semi_prior(unsupervised_z.contiguous(), supervised_z.contiguous(), y.contiguous(),
                                   self.component_size, self._causal_desc(), self.semisupervised_em_iters,
@@ -105,7 +128,7 @@ class _GMVAEBase(nn.Module):
     # ------------------------------------------------------------------ shared tails
     def _kl_and_h(self, q_z, q_z4_logq, q_eps, A, h_lambda, h_c, a_lambda, init_idx, extras):
         B = q_z.shape[0]
-        pi_k, mu_k, trace_k, _ = self.get_unsupervised_prior(q_z, init_idx)
+        pi_k, mu_k, trace_k, _ = self._unsup_prior(q_z, init_idx)
         # prior term with gradient to the causal parameters (mu_k, pi_k, trace_k are constants)
         q_eps_mu_k = self.causal(mu_k)
         logw = torch.log(pi_k) + self.gaussian_log_prob(
@@ -138,7 +161,7 @@ class _GMVAEBase(nn.Module):
             eps = self._draw_eps(q_mean, M)
         q_z, _ = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
         q_z = q_z.view(B, S * M, D)
-        pi_k, mu_k, trace_k, logw = self.get_unsupervised_prior(q_z, init_idx)
+        pi_k, mu_k, trace_k, logw = self._unsup_prior(q_z, init_idx)
         y_pred, _ = ops.posterior_argmax(q_z, mu_k, torch.zeros_like(mu_k), logw, S, M, want_post=False)
         return y_pred
 
@@ -155,7 +178,7 @@ class _GMVAEBase(nn.Module):
         uz = q_z[:, tr:tr + te].reshape(B, te * Mt, D).contiguous()
         sz = q_z[:, :tr].reshape(B, tr * Mt, D).contiguous()
         y = y_tr.reshape(B * tr)[:, None].repeat(1, Mt).view(B, tr * Mt)
-        pi_k, mu_k, lv_k, trace, logw = self.get_semisupervised_prior(uz, sz, y)
+        pi_k, mu_k, lv_k, trace, logw = self._semi_prior(uz, sz, y)
         y_pred, post = ops.posterior_argmax(uz, mu_k, lv_k, logw, te, Mt, want_post=extras is not None)
         if extras is not None:
             extras.update(pi_k=pi_k, mu_k=mu_k, logvar_k=lv_k, post_mean=post, q_z=q_z)
@@ -257,7 +280,7 @@ class OmniglotGMVAE(_GMVAEBase):
             uz = q_z[:, tr:tr + te].reshape(B, te * Mt, D).contiguous()
             sz = q_z[:, :tr].reshape(B, tr * Mt, D).contiguous()
             y = y_tr.reshape(B * tr)[:, None].repeat(1, Mt).view(B, tr * Mt)
-            pi_k, mu_k, lv_k, trace, logw = self.get_semisupervised_prior(uz, sz, y)
+            pi_k, mu_k, lv_k, trace, logw = self._semi_prior(uz, sz, y)
             z_to = uz.view(B, te, Mt, D)[0, :, 0, :].clone()
             Recon_X = self._decode(z_to)
             Component_X = self._decode(mu_k[0].contiguous())

@@ -6,6 +6,7 @@ device pointers and the current HIP stream through ctypes.  No CPU fallback exis
 tensors raise.
 """
 import ctypes
+import os
 
 import torch
 
@@ -34,6 +35,20 @@ def _req(t, name, dtype=torch.float32, shape=None):
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise RuntimeError('cmvae_amd: %s has shape %s, expected %s' % (name, tuple(t.shape), tuple(shape)))
     return t
+
+
+# CMVAE_CHECK_INDICES=1: range-check EM seeds and few-shot labels that already live on the GPU (one device sync per
+# call; off by default).  Indices that originate on the host are always checked before upload (model.py).
+CHECK_INDICES = os.environ.get('CMVAE_CHECK_INDICES', '0') not in ('', '0')
+
+
+def check_index_range(t, hi, name):
+    """Raise if any entry of the integer tensor / array lies outside [0, hi)."""
+    if (t.numel() if hasattr(t, 'numel') else t.size) == 0:
+        return
+    lo_v, hi_v = int(t.min()), int(t.max())
+    if lo_v < 0 or hi_v >= hi:
+        raise RuntimeError('cmvae_amd: %s has entries in [%d, %d], outside [0, %d)' % (name, lo_v, hi_v, hi))
 
 
 class Causal:
@@ -101,6 +116,10 @@ def unsup_prior(z, init_idx, causal, iters, fix_pi=False, gamma1=1.0):
     K = init_idx.shape[1]
     if not (1 <= K <= 32):
         raise RuntimeError('cmvae_amd: K=%d outside [1,32]' % K)
+    if K > N:
+        raise RuntimeError('cmvae_amd: K=%d seeds from N=%d latents' % (K, N))
+    if CHECK_INDICES:
+        check_index_range(init_idx, N, 'init_idx')
     ws_bytes = lib.cmvae_unsup_prior_workspace_bytes(B, N, K)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=z.device)
     pi = torch.empty(B, K, device=z.device); tau = torch.empty(B, K, device=z.device)
@@ -136,6 +155,8 @@ def semi_prior(uz, sz, y, K, causal, iters, gamma1=1.0):
         raise RuntimeError('cmvae_amd: y must be [B,Ns] int64 labels')
     if not (1 <= K <= 32):
         raise RuntimeError('cmvae_amd: K=%d outside [1,32]' % K)
+    if CHECK_INDICES:
+        check_index_range(y, K, 'y (support labels)')
     ws_bytes = lib.cmvae_semi_prior_workspace_bytes(B, Nu, Ns, K)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=uz.device)
     dev = uz.device

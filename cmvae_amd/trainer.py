@@ -48,7 +48,7 @@ class Trainer(object):
         self.stream = TrainStream(self.data.train_pool(), args.batch_size * args.sample_size)
         self.input_shape = self.data.input_shape
         self.model = self._new_model()
-        self.flat = cdist.FlatGrads(self.model.parameters())
+        self.flat = cdist.FlatGrads(self.model.parameters()).overlap_tail(self.model.tail_param_count())
         self.optimizer = FlatAdam(self.flat, lr=args.lr, weight_decay=args.weight_decay)
         self.seeds = cdist.SeedUploader((self.local_batch, args.way), self.device)
         self.log_interval = max(1, int(getattr(args, 'log_interval', 50)))
@@ -82,7 +82,12 @@ class Trainer(object):
         X = X.view(a.batch_size, a.sample_size, *shape)[cdist.shard_slice(a.batch_size, self.rank, self.world)]
         idx = cdist.draw_em_init(a.sample_size * a.train_mc_sample_size, a.way, a.batch_size, self.rank, self.world)
         idx = self.seeds.upload(idx)
-        X_rec, rec_loss, kl_loss, h_augment, h = self.model(X, h_lambda, h_c, a_lambda, init_idx=idx)
+        eps = None
+        if self.world > 1:
+            # every rank holds the same generator state: draw the global noise and keep this rank's episodes
+            eps = cdist.draw_eps(a.batch_size, a.sample_size, a.train_mc_sample_size, a.latent_size, self.device,
+                                 self.rank, self.world)
+        X_rec, rec_loss, kl_loss, h_augment, h = self.model(X, h_lambda, h_c, a_lambda, eps=eps, init_idx=idx)
         (rec_loss + kl_loss + h_augment).backward()
         self.flat.allreduce()
         self.optimizer.step()
@@ -124,7 +129,10 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, shot, accuracy, epoch, step):
-        path = os.path.join(self.args.save_dir, '%dshot_best_%s.pth' % (shot, step))
+        # file names as the reference writes them: omniglot/trainer.py:146,162 ('<shot>shot_best_<step>.pth'),
+        # mimgnet/trainer.py:134 and celeba/trainer.py ('5shot_best.pth')
+        name = '%dshot_best_%s.pth' % (shot, step) if self.variant == 'omniglot' else '%dshot_best.pth' % shot
+        path = os.path.join(self.args.save_dir, name)
         if self.rank == 0:
             torch.save({'state_dict': self.model.state_dict(), 'accuracy': accuracy, 'epoch': epoch,
                         'optimizer': self.optimizer.state_dict()}, path)
@@ -134,7 +142,7 @@ class Trainer(object):
         state = torch.load(path, map_location=self.device, weights_only=True)
         self.model = self._new_model()
         self.model.load_state_dict(state['state_dict'])
-        self.flat = cdist.FlatGrads(self.model.parameters())
+        self.flat = cdist.FlatGrads(self.model.parameters()).overlap_tail(self.model.tail_param_count())
         self.optimizer = FlatAdam(self.flat, lr=self.args.lr, weight_decay=self.args.weight_decay)
         if resume_optimizer and 'optimizer' in state:
             self.optimizer.load_state_dict(state['optimizer'])

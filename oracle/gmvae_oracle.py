@@ -89,7 +89,13 @@ def h_a(A, latent):
 
 
 # ----------------------------------------------------------------------------- set attention
-def mab(X, P, prefix, heads=4):
+def _tap(taps, name, t):
+    """Record the input of a non-smooth op (ReLU / max-pool) so a test can compare the masks of two runs."""
+    if taps is not None:
+        taps.setdefault(name, []).append(t.detach())
+
+
+def mab(X, P, prefix, heads=4, taps=None):
     q = F.linear(X, P[prefix + '.mab.fc_q.weight'], P[prefix + '.mab.fc_q.bias'])
     k = F.linear(X, P[prefix + '.mab.fc_k.weight'], P[prefix + '.mab.fc_k.bias'])
     v = F.linear(X, P[prefix + '.mab.fc_v.weight'], P[prefix + '.mab.fc_v.bias'])
@@ -100,13 +106,15 @@ def mab(X, P, prefix, heads=4):
     v_ = torch.cat(v.split(ds, 2), 0)
     a = torch.softmax(q_.bmm(k_.transpose(1, 2)) / math.sqrt(dim_v), 2)
     o = torch.cat((q_ + a.bmm(v_)).split(q.size(0), 0), 2)
-    o = o + F.relu(F.linear(o, P[prefix + '.mab.fc_o.weight'], P[prefix + '.mab.fc_o.bias']))
+    pre = F.linear(o, P[prefix + '.mab.fc_o.weight'], P[prefix + '.mab.fc_o.bias'])
+    _tap(taps, 'linear_relu', pre)
+    o = o + F.relu(pre)
     return o
 
 
-def q_z_given_h(H, P):
-    o = mab(H, P, 'q_z_given_H.0')
-    o = mab(o, P, 'q_z_given_H.1')
+def q_z_given_h(H, P, taps=None):
+    o = mab(H, P, 'q_z_given_H.0', taps=taps)
+    o = mab(o, P, 'q_z_given_H.1', taps=taps)
     return F.linear(o, P['q_z_given_H.2.weight'], P['q_z_given_H.2.bias'])
 
 
@@ -125,32 +133,37 @@ def _bn(x, P, name, training, running=None):
     return y
 
 
-def omniglot_encoder(x, P, training, running=None):
+def omniglot_encoder(x, P, training, running=None, taps=None):
     h = x
     for conv, bn in ((0, 1), (4, 5), (8, 9), (12, 13)):
         h = F.conv2d(h, P['encoder.encoder.%d.weight' % conv], P['encoder.encoder.%d.bias' % conv],
                      stride=1, padding=1)
         h = _bn(h, P, 'encoder.encoder.%d' % bn, training, running)
+        _tap(taps, 'enc_bn', h)
         h = F.relu(h)
         h = F.max_pool2d(h, 2, ceil_mode=True)
     return h.view(h.shape[0], -1)
 
 
-def omniglot_decoder(h, P, training, hidden=64, running=None):
+def omniglot_decoder(h, P, training, hidden=64, running=None, taps=None):
     x = h.view(-1, hidden, 2, 2)
     spec = ((0, 1, 4), (3, 4, 3), (6, 7, 4))
     for conv, bn, k in spec:
         x = F.conv_transpose2d(x, P['decoder.decoder.%d.weight' % conv], P['decoder.decoder.%d.bias' % conv],
                                stride=2, padding=1)
         x = _bn(x, P, 'decoder.decoder.%d' % bn, training, running)
+        _tap(taps, 'dec_bn', x)
         x = F.relu(x)
     x = F.conv_transpose2d(x, P['decoder.decoder.9.weight'], P['decoder.decoder.9.bias'], stride=2, padding=1)
     return torch.sigmoid(x)
 
 
-def proj(x, P, act):
+def proj(x, P, act, taps=None):
     for i in (0, 2, 4):
-        x = act(F.linear(x, P['proj.%d.weight' % i], P['proj.%d.bias' % i]))
+        x = F.linear(x, P['proj.%d.weight' % i], P['proj.%d.bias' % i])
+        if act is F.relu:
+            _tap(taps, 'linear_relu', x)
+        x = act(x)
     return x
 
 
@@ -181,6 +194,7 @@ class OracleGMVAE:
         self.gamma1 = 1 / math.sqrt(gamma)
         self.training = True
         self.running = {}
+        self.taps = None          # set to a dict to record the inputs of every ReLU / max-pool of a forward
         any_param = next(iter(P.values()))
         ref = P['q_z_given_H.2.weight']
         self.I = torch.eye(latent_size, dtype=ref.dtype)
@@ -320,11 +334,11 @@ class OracleGMVAE:
     def encode(self, X):
         B, S = X.shape[:2]
         if self.variant == 'omniglot':
-            H = omniglot_encoder(X.reshape(-1, *self.input_shape), self.P, self.training, self.running)
+            H = omniglot_encoder(X.reshape(-1, *self.input_shape), self.P, self.training, self.running, self.taps)
             H = H.view(B, S, self.last_hidden)
         else:
             H = X
-        return q_z_given_h(H, self.P).split(self.D, dim=-1)
+        return q_z_given_h(H, self.P, self.taps).split(self.D, dim=-1)
 
     # -- the training forward
     def forward(self, X, h_lambda, h_c, a_lambda, eps=None, init_idx=None, extras=None):
@@ -340,12 +354,12 @@ class OracleGMVAE:
         h_in = torch.cat([q_z, q_eps], -1).view(-1, 2 * D)
         if self.variant == 'omniglot':
             H_rec = proj(h_in, self.P, F.elu)
-            X_rec = omniglot_decoder(H_rec, self.P, self.training, self.hidden, self.running)
+            X_rec = omniglot_decoder(H_rec, self.P, self.training, self.hidden, self.running, self.taps)
             X_rec = X_rec.view(B, S, M, *self.input_shape)
             rec_loss = F.binary_cross_entropy(
                 X_rec, X[:, :, None, :, :, :].repeat(1, 1, M, 1, 1, 1), reduction='sum') / (B * S * M)
         else:
-            H_rec = proj(h_in, self.P, F.relu).view(B, S, M, self.input_shape)
+            H_rec = proj(h_in, self.P, F.relu, self.taps).view(B, S, M, self.input_shape)
             X_rec = H_rec
             Hrep = X[:, :, None, :].repeat(1, 1, M, 1)
             rec_loss = F.mse_loss(H_rec, Hrep, reduction='sum') / (B * S * M)

@@ -76,3 +76,19 @@ def test_state_dict_keys_and_param_count():
     f = FeatureGMVAE(input_shape=256)
     assert 'causal.A' in f.state_dict() and 'log_2' not in f.state_dict()
     assert tuple(f.state_dict()['causal.A'].shape) == (64, 64)
+
+
+def test_size_queries_survive_degenerate_shapes():
+    """Host-only size queries with zero-sized shapes.  A 5-way episode with sample-size 5 has te = 0 query items, so
+    Nu = 0 reached the tile partition in round 1 and died with SIGFPE (integer division by zero in the host code);
+    the queries must return a size, the entry points reject the shape (tests/test_gpu_kernels.py)."""
+    from cmvae_amd._lib import lib
+    assert lib.cmvae_unsup_prior_workspace_bytes(2, 0, 5) > 0
+    assert lib.cmvae_semi_prior_workspace_bytes(2, 0, 5, 5) > 0
+    assert lib.cmvae_semi_prior_workspace_bytes(2, 10, 0, 5) > 0
+    assert lib.cmvae_semi_prior_workspace_bytes(0, 0, 0, 5) >= 0
+    assert lib.cmvae_mixture_workspace_bytes(2, 0, 5) >= 0
+    for q in (lib.cmvae_conv_wgrad_workspace_bytes(0), lib.cmvae_linear_bwd_workspace_bytes(0, 64, 64),
+              lib.cmvae_conv_gemm_grid(0, 1), lib.cmvae_rowpass_grid(0), lib.cmvae_dec_out_grid(0),
+              lib.cmvae_causal_lc_bwd_grid(0), lib.cmvae_center_rows_chunks(0)):
+        assert q >= 0

@@ -20,8 +20,8 @@ def _free_port():
 
 class EpisodeBatchNorm2d(nn.BatchNorm2d):
     def forward(self, x):
-        from cmvae_amd import dist as cdist
-        return cdist.sync_batch_norm(x, self) if self.training else super().forward(x)
+        from tests.sync_bn_reference import sync_batch_norm
+        return sync_batch_norm(x, self) if self.training else super().forward(x)
 
 
 def _net():
@@ -42,21 +42,36 @@ def _worker(rank, world, port, out):
     r, w = cdist.init_from_env('gloo')
     assert (r, w) == (rank, world)
     net = _net().train()
-    flat = cdist.FlatGrads(net.parameters())
+    flat = cdist.FlatGrads(net.parameters()).overlap_tail(4)      # second conv + second BatchNorm: the tail bucket
     x = _data()[cdist.shard_slice(8)]
     flat.zero()
     y = net(x)
     loss = (y ** 2).mean()                       # a mean over an equal-sized shard
     loss.backward()
+    assert flat._tail_done and flat._tail_off == 4 * 9 + 4 + 4 + 4      # the tail went out during backward
+    flat.allreduce()
+    # a second step whose tail gets no gradient for one parameter falls back to one exchange of everything
+    flat.zero()
+    (net[0](x) ** 2).mean().backward()
+    assert not flat._tail_done
+    flat.allreduce()
+    g_partial = flat.flat.clone()
+    flat.zero()
+    loss = (net(x) ** 2).mean()
+    loss.backward()
     flat.allreduce()
     np.random.seed(77)
     idx = cdist.draw_em_init(50, 3, 8)
+    # reparametrisation noise: same generator state on both ranks -> disjoint slices of the single-process draw
+    torch.manual_seed(5)
+    eps = cdist.draw_eps(8, 3, 2, 4, 'cpu')
     # evaluation: 3 calls of a global batch of 4 episodes, 2 per rank; value = global episode number
     mine = torch.tensor([4.0 * t + 2 * rank + j for t in range(3) for j in range(2)])
     gathered = cdist.gather_episode_values(mine, 2)
     assert gathered.tolist() == [float(i) for i in range(12)], gathered
     out[rank] = dict(y=y.detach(), grad=flat.flat.clone(), rm=net[1].running_mean.clone(),
-                     rv=net[4].running_var.clone(), idx=idx, after=np.random.rand())
+                     rv=net[4].running_var.clone(), idx=idx, after=np.random.rand(), eps=eps.clone(),
+                     g_partial=g_partial)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -71,15 +86,24 @@ def test_two_rank_step_equals_single_process():
     net = _net().train()
     flat = cdist.FlatGrads(net.parameters())
     flat.zero()
-    y = net(_data())
-    (y ** 2).mean().backward()
+    (net[0](_data()) ** 2).mean().backward()
     flat.pack()
+    g_partial = flat.flat.clone()
+    for _ in range(2):                                 # the workers ran two full training-mode forwards
+        flat.zero()
+        y = net(_data())
+        (y ** 2).mean().backward()
+        flat.pack()
     got_y = torch.cat([out[0]['y'], out[1]['y']], 0)
     assert torch.allclose(got_y, y.detach(), atol=1e-5)
     for r in range(world):
         assert torch.allclose(out[r]['grad'], flat.flat, atol=1e-5), (out[r]['grad'] - flat.flat).abs().max()
         assert torch.allclose(out[r]['rm'], net[1].running_mean, atol=1e-6)
         assert torch.allclose(out[r]['rv'], net[4].running_var, atol=1e-6)
+    for r in range(world):
+        assert torch.allclose(out[r]['g_partial'], g_partial, atol=1e-5)
+    torch.manual_seed(5)
+    assert torch.equal(torch.cat([out[0]['eps'], out[1]['eps']], 0), torch.randn(8, 3, 2, 4))
     # EM seeds: every rank drew the global stream and kept its own slice
     np.random.seed(77)
     ref = np.stack([np.random.choice(50, 3, replace=False) for _ in range(8)], 0)

@@ -55,13 +55,14 @@ def _worker(rank, world, port, out):
     cdist.init_from_env('gloo')
     device = torch.device('cuda:0')
     model = _build(device)
-    flat = cdist.FlatGrads(model.parameters())
+    flat = cdist.FlatGrads(model.parameters()).overlap_tail(model.tail_param_count())    # decoder + proj bucket
     opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
     X, eps = _inputs()
     sl = cdist.shard_slice(B)
     np.random.seed(21)
     idx = cdist.draw_em_init(S * M, K, B)
     losses, grads = _step(model, flat, opt, X[sl], eps[sl], idx, device)
+    assert flat._tail_off < flat.flat.numel()          # the tail bucket exists; _step's allreduce consumed it
     out[rank] = dict(losses=losses, grads=grads, w=model.proj[0].weight.detach().cpu().clone(),
                      rm=model.decoder.decoder[1].running_mean.detach().cpu().clone())
     torch.distributed.barrier()

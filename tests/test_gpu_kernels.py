@@ -123,8 +123,12 @@ def test_semi_prior_trajectory(device, K, Nu, Ns, linear, gamma):
         pi, mu, lv, tau, logw = ops.semi_prior(uz.to(device), sz.to(device), y.to(device), K, c, it, model.gamma1)
         rpi, rmu, rlv, rtau = traj[it]
         assert rel_err(mu, rmu) < RTOL, 'mu after %d iterations' % it
-        assert rel_err(lv, rlv) < 5 * RTOL, 'logvar after %d iterations' % it   # log of a small variance
+        # |d logvar| is the element-wise relative error of the variance: the 1e-4 bar applies to it directly, and
+        # norm-wise to the variance and to logvar
+        print('  it %d: logvar norm-rel %.2e  max|d logvar| %.2e' % (it, rel_err(lv, rlv), float((lv.cpu() - rlv).abs().max())))
         assert rel_err(lv.exp(), rlv.exp()) < RTOL
+        assert float((lv.cpu() - rlv).abs().max()) < RTOL, 'variance element-wise after %d iterations' % it
+        assert rel_err(lv, rlv) < RTOL, 'logvar after %d iterations' % it
         assert rel_err(pi, rpi) < 1e-6 and rel_err(tau, rtau) < 1e-6
 
 
@@ -219,3 +223,69 @@ def test_missing_gpu_tensor_raises(device):
     from cmvae_amd import ops
     with pytest.raises(RuntimeError):
         ops.mixture_loglik(torch.zeros(1, 4, 64), torch.zeros(1, 2, 64), torch.zeros(1, 2))
+
+
+def test_empty_episodes_are_rejected_not_launched(device):
+    """Regression for the round-1 SIGFPE (gpurun_out/t4.log): S=5, K=5 leaves no query items (Nu = 0).  Both the
+    Python shims and the C-ABI entry points must refuse N == 0 / Nu == 0 / Ns == 0 with an error, not crash."""
+    from cmvae_amd import ops
+    from cmvae_amd._lib import lib
+    model, _ = build_pair('feat', K=5, linear=True)
+    c = _causal_desc(model, device)
+    z0 = torch.zeros(2, 0, 64, device=device)
+    z = torch.randn(2, 10, 64, device=device)
+    y = torch.zeros(2, 10, dtype=torch.int64, device=device)
+    with pytest.raises(RuntimeError):
+        ops.semi_prior(z0, z, y, 5, c, 2)
+    with pytest.raises(RuntimeError):
+        ops.semi_prior(z, z0, torch.zeros(2, 0, dtype=torch.int64, device=device), 5, c, 2)
+    with pytest.raises(RuntimeError):
+        ops.unsup_prior(z0, torch.zeros(2, 5, dtype=torch.int64, device=device), c, 2)
+    with pytest.raises(RuntimeError):
+        ops.unsup_prior(z[:, :3].contiguous(), torch.zeros(2, 5, dtype=torch.int64, device=device), c, 2)   # K > N
+    # straight through the C-ABI: error code and message, nothing launched
+    out = [torch.full((2, 5), 3.0, device=device) for _ in range(3)]
+    mu, lv = torch.full((2, 5, 64), 3.0, device=device), torch.full((2, 5, 64), 3.0, device=device)
+    ws = torch.empty(lib.cmvae_semi_prior_workspace_bytes(2, 0, 10, 5), dtype=torch.uint8, device=device)
+    rc = lib.cmvae_semi_prior(z.data_ptr(), z.data_ptr(), y.data_ptr(), 2, 0, 10, 5, c.ref, 2, 1.0, ws.data_ptr(),
+                              ws.numel(), out[0].data_ptr(), mu.data_ptr(), lv.data_ptr(), out[1].data_ptr(),
+                              out[2].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b'bad shape' in lib.cmvae_last_error()
+    idx = torch.zeros(2, 5, dtype=torch.int64, device=device)
+    rc = lib.cmvae_unsup_prior(z.data_ptr(), 2, 0, 5, idx.data_ptr(), c.ref, 2, 0, 1.0, ws.data_ptr(), ws.numel(),
+                               out[0].data_ptr(), mu.data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+    assert rc != 0
+    torch.cuda.synchronize()
+    assert float(mu.min()) == 3.0
+    # a model-level call with no query items says so as well
+    with pytest.raises(RuntimeError):
+        model.to(device).eval()
+        H = torch.relu(torch.randn(2, 5, 256, device=device))
+        model.prediction(H, torch.arange(5, device=device)[None].repeat(2, 1), H[:, :0])
+
+
+def test_out_of_range_seeds_and_labels(device):
+    """init_idx >= N is clamped inside the kernel (never an out-of-bounds read) and rejected on the host when the
+    indices come from the CPU; labels outside [0, K) are rejected on the host path."""
+    from cmvae_amd import ops
+    model, _ = build_pair('feat', K=3, linear=True)
+    c = _causal_desc(model, device)
+    model.to(device)
+    z = torch.randn(2, 50, 64, device=device)
+    bad = torch.tensor([[0, 1, 50], [3, -1, 7]], dtype=torch.int64)
+    pi, mu, tau, logw = ops.unsup_prior(z, bad.to(device), c, 1)             # device tensor: clamped, finite
+    assert torch.isfinite(mu).all()
+    with pytest.raises(RuntimeError):
+        model._unsup_prior(z, bad.numpy())                                    # host indices: checked before upload
+    with pytest.raises(RuntimeError):
+        model._semi_prior(z, z, torch.full((2, 50), 3, dtype=torch.int64))    # label 3 with K = 3
+    old = ops.CHECK_INDICES
+    ops.CHECK_INDICES = True
+    try:
+        with pytest.raises(RuntimeError):
+            ops.unsup_prior(z, bad.to(device), c, 1)
+        with pytest.raises(RuntimeError):
+            ops.semi_prior(z, z, torch.full((2, 50), 3, dtype=torch.int64, device=device), 3, c, 1)
+    finally:
+        ops.CHECK_INDICES = old

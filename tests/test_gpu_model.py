@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import build_pair, omniglot_batch, feature_batch, rel_err, RTOL
+from tests.helpers import build_pair, omniglot_batch, feature_batch, rel_err, max_rel, em_elementwise_check, RTOL
 
 pytestmark = pytest.mark.gpu
 
@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 def _run_forward_pair(model, oracle, X, eps, idx, device, hl=0.1, hc=0.1, al=1e-4):
     # oracle (CPU) with autograd on a private trainable copy of the weights
     from oracle.gmvae_oracle import make_trainable, OracleGMVAE
+    from cmvae_amd import encoder as _enc, decoder as _dec, linear as _lin
     # the same oracle in fp64: tells how far fp32 rounding alone moves the gradients of this problem
     P64 = make_trainable({k: (v.double() if v.is_floating_point() else v) for k, v in oracle.P.items()})
     o64 = OracleGMVAE(P64, oracle.variant, input_shape=oracle.input_shape, unsupervised_em_iters=oracle.unsup_iters,
@@ -23,13 +24,58 @@ def _run_forward_pair(model, oracle, X, eps, idx, device, hl=0.1, hc=0.1, al=1e-
     oracle.P64 = P64
     oracle.P = make_trainable(oracle.P)
     ex_o = {}
+    oracle.taps = {}
     out_o = oracle.forward(X, hl, hc, al, eps=eps, init_idx=idx, extras=ex_o)
+    ex_o['init_idx'] = idx
     (out_o[1] + out_o[2] + out_o[3]).backward()
     model.to(device).train()
     ex_g = {}
-    out_g = model(X.to(device), hl, hc, al, eps=eps.to(device), init_idx=torch.from_numpy(idx).to(device), extras=ex_g)
+    taps_g = {}
+    _enc.TAPS = _dec.TAPS = _lin.TAPS = taps_g
+    try:
+        out_g = model(X.to(device), hl, hc, al, eps=eps.to(device), init_idx=torch.from_numpy(idx).to(device),
+                      extras=ex_g)
+    finally:
+        _enc.TAPS = _dec.TAPS = _lin.TAPS = None
     (out_g[1] + out_g[2] + out_g[3]).backward()
+    ex_g['taps'], ex_o['taps'] = taps_g, oracle.taps
     return out_o, ex_o, out_g, ex_g
+
+
+def _nchw(y, fold, n):
+    """Pre-BatchNorm channels-last rows [n*H*W,64] + fold -> BatchNorm output [n,64,H,W] on the CPU."""
+    hw = y.shape[0] // n
+    H = int(round(hw ** 0.5))
+    pre = y * fold[0] + fold[1]
+    return pre.view(n, H, H, 64).permute(0, 3, 1, 2).cpu()
+
+
+def _mask_flips(taps_g, taps_o):
+    """Number of ReLU sign decisions and max-pool winners on which the HIP run and the oracle run differ.
+    A unit whose pre-activation lies within fp32 rounding of zero (or a pooling window whose two largest entries
+    lie that close together) can legitimately go either way; everything upstream of it then sees a different
+    gradient."""
+    import torch.nn.functional as F
+    flips = 0
+    if 'enc' in taps_g:
+        ys, folds = taps_g['enc']
+        n = taps_o['enc_bn'][0].shape[0]
+        for y, fold, pre_o in zip(ys, folds, taps_o['enc_bn']):
+            pre_g = _nchw(y, fold, n)
+            flips += int(((pre_g > 0) != (pre_o > 0)).sum())
+            pg, ig = F.max_pool2d(F.relu(pre_g), 2, ceil_mode=True, return_indices=True)
+            po, io = F.max_pool2d(F.relu(pre_o), 2, ceil_mode=True, return_indices=True)
+            flips += int(((ig != io) & ((pg > 0) | (po > 0))).sum())
+    if 'dec' in taps_g:
+        acts, folds = taps_g['dec']
+        n = taps_o['dec_bn'][0].shape[0]
+        for y, fold, pre_o in zip(acts[1:], folds[1:], taps_o['dec_bn']):
+            flips += int(((_nchw(y, fold, n) > 0) != (pre_o > 0)).sum())
+    lg, lo = taps_g.get('linear_relu', []), taps_o.get('linear_relu', [])
+    assert len(lg) == len(lo)
+    for y_g, pre_o in zip(lg, lo):
+        flips += int(((y_g.cpu() > 0) != (pre_o.reshape(y_g.shape) > 0)).sum())
+    return flips
 
 
 def _check_forward(model, oracle, out_o, ex_o, out_g, ex_g):
@@ -42,7 +88,10 @@ def _check_forward(model, oracle, out_o, ex_o, out_g, ex_g):
     assert rel_err(out_g[0], out_o[0]) < RTOL                               # reconstructions
     for key in ('q_z_mean', 'q_z_logvar', 'mu_k', 'pi_k', 'log_p_z', 'log_q_z', 'log_p_eps'):
         assert rel_err(ex_g[key].reshape(-1), ex_o[key].reshape(-1)) < RTOL, key
-    return _grad_report(model, oracle)
+    # element-wise on the EM parameters, anchored on the fp64 EM (tests/helpers.py)
+    em_elementwise_check(oracle, ex_g, ex_o, ex_o['init_idx'], verbose=False)
+    strict_ok, worst = _grad_report(model, oracle)
+    return strict_ok, worst, _mask_flips(ex_g['taps'], ex_o['taps'])
 
 
 def _grad_report(model, oracle):
@@ -71,14 +120,19 @@ def _grad_report(model, oracle):
 
 
 def _grad_parity_over_seeds(run):
-    """Forward parity must hold for every seed.  Gradients: on these tiny batches one ReLU / max-pool
-    decision sitting within fp32 rounding of zero can flip between two correct fp32 implementations and
-    move every upstream gradient by ~1/N (seen: 4e-3 for one flip among 48 images).  Bar: within 2e-4 of
-    the fp32 oracle (or as close to the fp64 oracle as the fp32 oracle is, x4) on at least 2 of 3 seeds,
-    and never further than 2e-2."""
-    results = [run(seed) for seed in (1, 2, 3)]
-    assert all(w < 2e-2 for _, w in results), results
-    assert sum(ok for ok, _ in results) >= 2, results
+    """Forward parity must hold for every seed.  Gradients: every seed on which the HIP run and the oracle take the
+    same ReLU / max-pool decisions must match per tensor within 2e-4 of the fp32 oracle (or be as close to the fp64
+    oracle as the fp32 oracle is, x4).  On these tiny batches a pre-activation within fp32 rounding of zero can
+    legitimately fall on either side in two correct fp32 implementations, which moves every upstream gradient by
+    ~1/N (seen: 4e-3 for one flip among 48 images): a seed may miss the strict bar only if such a flip is actually
+    observed in the exported masks, and then stays within 2e-2.  At least two seeds must be flip-free so the strict
+    bar is exercised."""
+    results = [run(seed) for seed in (1, 2, 3, 4)]
+    print('  (strict_ok, worst, mask flips) per seed:', results)
+    for strict_ok, worst, flips in results:
+        assert worst < 2e-2, results
+        assert strict_ok or flips > 0, 'gradient mismatch without any ReLU / max-pool decision differing: %r' % (results,)
+    assert sum(1 for _, _, flips in results if flips == 0) >= 2, results
 
 
 @pytest.mark.parametrize('linear', [False, True])
@@ -139,7 +193,9 @@ def test_prediction_bit_exact(device, variant, linear, K, shot, query, M):
     assert y_g.dtype == torch.int64 and tuple(y_g.shape) == (B, te)
     assert rel_err(ex_g['mu_k'], ex_o['mu_k']) < RTOL
     assert rel_err(ex_g['logvar_k'].exp(), ex_o['logvar_k'].exp()) < RTOL
-    assert rel_err(ex_g['post_mean'], ex_o['post_mean']) < 10 * RTOL
+    assert rel_err(ex_g['logvar_k'], ex_o['logvar_k']) < RTOL
+    assert rel_err(ex_g['post_mean'], ex_o['post_mean']) < RTOL
+    assert max_rel(ex_g['mu_k'], ex_o['mu_k'], floor=float(ex_o['mu_k'].abs().max()) * 1e-2) < 5 * RTOL
     assert torch.equal(y_g.cpu(), y_o), 'few-shot assignments must be bit-exact'
 
 
