@@ -44,6 +44,9 @@ SIGNATURES = {
     'cmvae_unsup_prior_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cmvae_unsup_prior': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, _PC, c_int, c_int, c_float,
                                   c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_unsup_prior_noalloc_max_bytes': (c_size_t, []),
+    'cmvae_unsup_prior_noalloc': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, _PC, c_int, c_int, c_float,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cmvae_em_pass': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                               ctypes.POINTER(c_int), c_void_p]),
     'cmvae_semi_prior_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -10,6 +10,7 @@
 #ifndef CMVAE_ABLATE_EM
 #define CMVAE_ABLATE_EM 0      // profiling builds only: 1 = no distance loops, 2 = no M-step MFMA
 #endif
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -1001,6 +1002,53 @@ extern "C" int cmvae_unsup_prior(const float* z, int B, int N, int K, const int6
     EmWorkspace w = carve(workspace, B, N, 0, K, false);
     CMVAE_REQUIRE(workspace && workspace_bytes >= w.bytes, "cmvae_unsup_prior: workspace %zu < %zu", workspace_bytes,
                   w.bytes);
+    return unsup_prior_run(z, B, N, K, init_idx, c, iters, fix_pi, gamma1, w, pi, mu, tau, logw, (hipStream_t)stream);
+}
+
+// ---- the same loop for callers that cannot allocate (HIP graph capture, serving loops): the workspace is a
+// file-scope device array.  Its name is a host-side stand-in, never a device address: every use below goes through
+// the per-device pointer hipGetSymbolAddress returned (each GPU holds its own copy of the array).
+static __device__ __align__(256) unsigned char scratch[CMVAE_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices];     // per device, filled on the first call on that device
+std::mutex g_scratch_mutex;
+
+int scratch_pointer(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return cmvae::set_error("cmvae_unsup_prior_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return cmvae::set_error("cmvae_unsup_prior_noalloc: device %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return cmvae::set_error("cmvae_unsup_prior_noalloc: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t cmvae_unsup_prior_noalloc_max_bytes(void) { return CMVAE_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int cmvae_unsup_prior_noalloc(const float* z, int B, int N, int K, const int64_t* init_idx,
+                                         const cmvae_causal* c, int iters, int fix_pi, float gamma1, float* pi,
+                                         float* mu, float* tau, float* logw, void* stream) {
+    cmvae::clear_stale_error();
+    if (int e = unsup_prior_check(z, B, N, K, init_idx, c, iters, pi, mu, tau, logw)) return e;
+    const size_t need = carve(nullptr, B, N, 0, K, false).bytes;
+    CMVAE_REQUIRE(need <= (size_t)CMVAE_NOALLOC_SCRATCH_BYTES,
+                  "cmvae_unsup_prior_noalloc: B=%d N=%d K=%d needs %zu bytes of scratch, the static buffer holds %zu "
+                  "(use cmvae_unsup_prior with a caller workspace)", B, N, K, need, (size_t)CMVAE_NOALLOC_SCRATCH_BYTES);
+    void* base = nullptr;
+    if (int e = scratch_pointer(&base)) return e;
+    // nothing in the workspace has to start at zero: every partial-sum slot that a finalize launch reads was written
+    // by the pass launch just before it, and both inverses are written before their first use
+    EmWorkspace w = carve(base, B, N, 0, K, false);
     return unsup_prior_run(z, B, N, K, init_idx, c, iters, fix_pi, gamma1, w, pi, mu, tau, logw, (hipStream_t)stream);
 }
 

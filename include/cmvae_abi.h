@@ -77,6 +77,20 @@ int cmvae_unsup_prior(const float* z, int B, int N, int K, const int64_t* init_i
                       void* workspace, size_t workspace_bytes,
                       float* pi, float* mu, float* tau, float* logw, void* stream);
 
+/* ---- cmvae_unsup_prior for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that may not call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  Same arguments, kernels and results as cmvae_unsup_prior, minus the workspace: the EM partial sums
+ * and the two Gram inverses live in a file-scope device array of CMVAE_NOALLOC_SCRATCH_BYTES that every GPU the
+ * library runs on holds until the process ends (its address is looked up once per device, on the first call on
+ * that device — make that call outside graph capture).  Shapes whose workspace
+ * (cmvae_unsup_prior_workspace_bytes) exceeds the array are rejected with an error; nothing is launched then.
+ * All calls on one GPU share the array: calls that overlap on one GPU (two streams, two host threads) race.   */
+#define CMVAE_NOALLOC_SCRATCH_BYTES (8u << 20)
+size_t cmvae_unsup_prior_noalloc_max_bytes(void);
+int cmvae_unsup_prior_noalloc(const float* z, int B, int N, int K, const int64_t* init_idx,
+                              const cmvae_causal* c, int iters, int fix_pi, float gamma1,
+                              float* pi, float* mu, float* tau, float* logw, void* stream);
+
 /* ---- one fused E-step + M-step pass over z (the loop body's hot kernel, exposed for
  * measurement and tests): responsibilities from (mu, logw) and per-block partial sums
  * part_N [B,nblk,32], part_S1 [B,nblk,K,64] in `workspace` (layout of cmvae_unsup_prior).
