@@ -29,7 +29,7 @@ class ConvGeom(ctypes.Structure):
                                               'oxs', 'oy0', 'ox0', 'ntaps', 'a_pitch', 'o_pitch', 'w_pitch')] + \
                [('w_nblk_stride', ctypes.c_int64),
                 ('dy', ctypes.c_int32 * 32), ('dx', ctypes.c_int32 * 32), ('a_col', ctypes.c_int32 * 32),
-                ('w_off', ctypes.c_int32 * 32)]
+                ('w_off', ctypes.c_int32 * 32), ('pixel_major', ctypes.c_int32)]
 
 
 _PG = ctypes.POINTER(ConvGeom)

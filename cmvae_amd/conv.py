@@ -19,9 +19,12 @@ def _stream():
 
 
 def _geom(rows, Hg, Wg, Hi, Wi, sy, sx, Ho, Wo, oys, oxs, oy0, ox0, taps, a_pitch, o_pitch, w_pitch, w_tap_stride,
-          w_nblk_stride=0, a_cols=None, w_taps=None):
-    """w_taps: index of each tap's 64x64 block in the weight tensor (default 0..ntaps-1)."""
+          w_nblk_stride=0, a_cols=None, w_taps=None, pixel_major=False):
+    """w_taps: index of each tap's 64x64 block in the weight tensor (default 0..ntaps-1).
+    pixel_major: rows enumerate (y, x, image) instead of (image, y, x): a 128-row tile then sits at one grid
+    position and the kernels skip the taps that fall outside the image for it (include/cmvae_abi.h)."""
     g = ConvGeom()
+    g.pixel_major = int(bool(pixel_major))
     g.rows_total, g.Hg, g.Wg, g.Hi, g.Wi, g.sy, g.sx = rows, Hg, Wg, Hi, Wi, sy, sx
     g.Ho, g.Wo, g.oys, g.oxs, g.oy0, g.ox0 = Ho, Wo, oys, oxs, oy0, ox0
     g.ntaps = len(taps)
@@ -60,7 +63,7 @@ def convT_phase_taps(k, py, px):
 
 
 @functools.lru_cache(maxsize=None)
-def geom_convT_phase(n, Hi, Wi, k, py, px, C=64):
+def geom_convT_phase(n, Hi, Wi, k, py, px, C=64, pixel_major=False):
     """One sub-pixel phase of ConvTranspose2d(k, stride 2, pad 1): [n,Hi,Wi,C] -> [n,Ho,Wo,C].
     Returns (geometry, tap_idx): the geometry's weight offsets address the FULL kernel [k*k][co][ci], tap t of
     the phase being kernel tap tap_idx[t] = ky*k + kx."""
@@ -69,12 +72,12 @@ def geom_convT_phase(n, Hi, Wi, k, py, px, C=64):
     taps = convT_phase_taps(k, py, px)
     tap_idx = [t[0] * k + t[1] for t in taps]
     g = _geom(n * Hg * Wg, Hg, Wg, Hi, Wi, 1, 1, Ho, Wo, 2, 2, py, px, [(t[2], t[3]) for t in taps], C, C, C, C * C,
-              w_taps=tap_idx)
+              w_taps=tap_idx, pixel_major=pixel_major)
     return g, tap_idx
 
 
 @functools.lru_cache(maxsize=None)
-def geom_convT_dgrad(n, Hi, Wi, k, C=64):
+def geom_convT_dgrad(n, Hi, Wi, k, C=64, pixel_major=False):
     """Data gradient of the transposed conv = stride-2 conv over d_out [n,Ho,Wo,C] -> [n,Hi,Wi,C].
     Returns (geometry, order): tap t of the geometry is kernel tap order[t] = ky*k + kx; the weight offsets
     address the full kernel [k*k][ci][co] in its natural order."""
@@ -84,7 +87,8 @@ def geom_convT_dgrad(n, Hi, Wi, k, C=64):
     kxs = [kx for par in (0, 1) for kx in range(par, k, 2)]
     order = [ky * k + kx for ky in range(k) for kx in kxs]
     taps = [(t // k - 1, t % k - 1) for t in order]
-    return _geom(n * Hi * Wi, Hi, Wi, Ho, Wo, 2, 2, Hi, Wi, 1, 1, 0, 0, taps, C, C, C, C * C, w_taps=order), order
+    return _geom(n * Hi * Wi, Hi, Wi, Ho, Wo, 2, 2, Hi, Wi, 1, 1, 0, 0, taps, C, C, C, C * C, w_taps=order,
+                 pixel_major=pixel_major), order
 
 
 @functools.lru_cache(maxsize=None)

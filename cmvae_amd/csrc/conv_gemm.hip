@@ -37,6 +37,16 @@ struct ConvGeom {
     int dy[32], dx[32];       // dword arrays: indexed by the (uniform) tap counter they stay in SGPRs
     int a_col[32];
     int w_off[32];            // float offset of tap t's 64x64 weight block
+    // pixel-major row order (0 = image-major): rows enumerate (y, x, image), r = (y*Wg + x)*pm_nimg + image.  A tile
+    // of consecutive rows then holds ONE grid position of many images, so a tap that falls outside the image does so
+    // for the whole tile and is skipped instead of multiplying zero padding (14 % of the taps of a 7x7 -> 14x14
+    // transposed convolution, 31 % at 4x4 -> 7x7, 44 % at 2x2 -> 4x4).  Measured on the layer-3 launches (38400
+    // images): forward phase 575 -> 512 us, weight gradient 635 -> 600 us; the 16-tap data gradient gains little
+    // (2.34 -> 2.32 ms: its 16 gathered row sets per tile no longer overlap inside a tile, the saved MFMAs go into
+    // memory traffic).  A class-major order (interior / edge / corner rectangles, image-major inside a class) was built
+    // and measured as well: it keeps the locality but its edge tiles (1-2 taps per 32 KB of operand and output) are
+    // bandwidth-bound and re-read the edge rows of the input: 545-570 / 650 / 2350 us, no better than image-major.
+    int pm_nimg;
 };
 
 struct RowInfo {
@@ -69,7 +79,49 @@ struct RowDecoder {
             f(e, n0 + dn, y, rem - y * wg);
         }
     }
+    // pixel-major order: r = pix * nimg + image.  Exact integer division: one or eight per lane and tile, next to
+    // the tile's hundreds of MFMAs.
+    template <int N, typename F>
+    __device__ __forceinline__ void decode_pm(int nimg, int r0, int step, F&& f) const {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const int r = r0 + step * e;
+            const int pix = (int)((unsigned)r / (unsigned)nimg);
+            const int y = small_div(pix, inv_wg);               // pix < Hg*Wg + a few tiles' worth: far below 2^21
+            f(e, r - pix * nimg, y, pix - y * wg);
+        }
+    }
 };
+
+// Taps tap0 .. tap0+ntaps-1 that are inside the image for at least one row of tile [row0, row0 + rows), as a bit mask
+// (wave-uniform scalar code).  Image-major order, a tile that spans two grid positions, or a tile with no valid tap
+// at all: every tap (rows are masked individually either way; the mask only removes work that is zero for the whole
+// tile).
+struct TileInfo { unsigned mask; };
+template <bool PM>
+__device__ __forceinline__ TileInfo tile_info(const ConvGeom& g, int row0, int rows, int tap0, int ntaps) {
+    const unsigned full = ntaps >= 32 ? 0xffffffffu : ((1u << ntaps) - 1u);
+    TileInfo ti{full};
+    if (!PM) return ti;
+    row0 = __builtin_amdgcn_readfirstlane(row0);
+    if (row0 >= g.rows_total) { ti.mask = 1u; return ti; }
+    int last = row0 + rows - 1;
+    if (last >= g.rows_total) last = g.rows_total - 1;
+    const int p0 = row0 / g.pm_nimg, p1 = last / g.pm_nimg;
+    if (p0 != p1) return ti;
+    const int y = p0 / g.Wg, x = p0 - y * g.Wg;
+    const int ys = y * g.sy, xs = x * g.sx;
+    unsigned m = 0;
+    for (int t = 0; t < ntaps; ++t) {
+        const bool in = ((unsigned)(ys + g.dy[tap0 + t]) < (unsigned)g.Hi) & ((unsigned)(xs + g.dx[tap0 + t]) < (unsigned)g.Wi);
+        m |= in ? (1u << t) : 0u;
+    }
+    ti.mask = __builtin_amdgcn_readfirstlane(m ? m : full);
+    return ti;
+}
+// lowest set bit at or above position `from` (mask has one): index; mask_above(m, t) = bits of m above t
+__device__ __forceinline__ int first_tap(unsigned m) { return __builtin_ctz(m); }
+__device__ __forceinline__ unsigned taps_above(unsigned m, int t) { return t >= 31 ? 0u : (m & ~((2u << t) - 1u)); }
 
 __device__ __forceinline__ RowInfo make_row(const ConvGeom& g, int r, int n, int y, int x) {
     RowInfo ri;
@@ -96,7 +148,6 @@ __device__ __forceinline__ int out_pixel(const ConvGeom& g, int r) {
     const int x = rem - y * g.Wg;
     return (n * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
 }
-
 // Load 4 channels of the source pixel of row `ri` for tap t; *ok says whether the tap is inside the image.
 // Branch-free: an outside tap loads element 0 (always mapped) and is zeroed by transform_a; a branch around
 // each load would make hipcc wait for every load separately.  Tap quantities are wave-uniform (SGPRs).
@@ -297,7 +348,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
 // tile and loads its operand directly in MFMA fragment layout (8 x 16 B: channels 8kk + 4h .. +3), one step ahead.
 // The operand never passes through LDS: no staging stores, no A-fragment reads, one row decode per lane, and the
 // two barriers of a step only guard the 16 KB weight tile.
-template <int ACT, bool LINEAR>
+template <int ACT, bool LINEAR, bool PM>
 __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, const float* __restrict__ A,
                                                                   const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias,
@@ -313,7 +364,6 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
     const float* Wn = Wt + nb * g.w_nblk_stride + (long)rb * g.w_pitch + 4 * q;
     const long w16 = 16L * g.w_pitch;
     const int ntiles = (g.rows_total + BM - 1) / BM;
-    const int nsteps = ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * g.ntaps;
     const RowDecoder dec(g);
     float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
     const float b0 = bias ? bias[nb * 64 + i] : 0.f;
@@ -321,14 +371,24 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 
     RowInfo ri;
     float4 ra[8], rw0, rw1, rw2, rw3;
-    int ltile = blockIdx.x, par = 0;
-    auto rows_of_tile = [&](int tile, int* op) {
+    int par = 0;
+    auto rows_of_tile = [&](int tile, const TileInfo& ti, int* op) {
         const int r = tile * BM + 32 * w + i;          // this lane's row
         if (LINEAR) {
             ri.off = r * g.a_pitch;
             ri.ys = r < g.rows_total ? 0 : INVALID_YS;
             ri.xs = 0;
             if (tid < BM) op[tid] = tile * BM + tid < g.rows_total ? tile * BM + tid : -1;
+        } else if (PM) {
+            dec.decode_pm<1>(g.pm_nimg, r, 0, [&](int, int n, int y, int x) { ri = make_row(g, r, n, y, x); });
+            if (tid < BM) {
+                const int ro = tile * BM + tid;
+                int opx = -1;
+                dec.decode_pm<1>(g.pm_nimg, ro, 0, [&](int, int n, int y, int x) {
+                    if (ro < g.rows_total) opx = (n * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
+                });
+                op[tid] = opx;
+            }
         } else {
             dec.decode<1>(r, 0, [&](int, int n, int y, int x) { ri = make_row(g, r, n, y, x); });
             if (tid < BM) op[tid] = out_pixel(g, tile * BM + tid);
@@ -346,18 +406,23 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
             ra[kk] = v;
         }
     };
-    rows_of_tile(ltile, opix[0]);
-    load_frag(0);
-    {
-        const float* Wn0 = Wn + g.w_off[0];
-        rw0 = *reinterpret_cast<const float4*>(Wn0);
-        rw1 = *reinterpret_cast<const float4*>(Wn0 + w16);
-        rw2 = *reinterpret_cast<const float4*>(Wn0 + 2 * w16);
-        rw3 = *reinterpret_cast<const float4*>(Wn0 + 3 * w16);
-    }
+    auto load_w = [&](int t) {
+        const float* Wn1 = Wn + g.w_off[t];
+        rw0 = *reinterpret_cast<const float4*>(Wn1);
+        rw1 = *reinterpret_cast<const float4*>(Wn1 + w16);
+        rw2 = *reinterpret_cast<const float4*>(Wn1 + 2 * w16);
+        rw3 = *reinterpret_cast<const float4*>(Wn1 + 3 * w16);
+    };
+    // one software pipeline over the block's (tile, valid tap) steps
+    int tile = blockIdx.x;
+    TileInfo ti = tile_info<PM>(g, tile * BM, BM, 0, g.ntaps);
+    unsigned mask = ti.mask;
+    int t = first_tap(mask);
+    rows_of_tile(tile, ti, opix[0]);
+    load_frag(t);
+    load_w(t);
     floatx16 acc0 = {}, acc1 = {};
-    int t = 0;
-    for (int s = 0; s < nsteps; ++s) {
+    while (tile < ntiles) {
         __syncthreads();
         *reinterpret_cast<float4*>(&Ws[rb * LDA + 4 * q]) = rw0;
         *reinterpret_cast<float4*>(&Ws[(rb + 16) * LDA + 4 * q]) = rw1;
@@ -367,20 +432,21 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) a[kk] = ra[kk];
         __syncthreads();
-        int tn = t + 1;
-        if (tn == g.ntaps) {
-            tn = 0;
-            ltile += gridDim.x;
-            rows_of_tile(ltile, opix[par ^ 1]);
+        const unsigned rest = taps_above(mask, t);
+        const bool last = rest == 0;                   // uniform: the tile's last valid tap
+        int tn, ntile = tile;
+        unsigned nmask = mask;
+        if (last) {
+            ntile = tile + gridDim.x;
+            ti = tile_info<PM>(g, ntile * BM, BM, 0, g.ntaps);
+            nmask = ti.mask;
+            tn = first_tap(nmask);
+            rows_of_tile(ntile, ti, opix[par ^ 1]);    // past the block's last tile every row is invalid: element 0
+        } else {
+            tn = first_tap(rest);
         }
         load_frag(tn);
-        {
-            const float* Wn1 = Wn + g.w_off[tn];
-            rw0 = *reinterpret_cast<const float4*>(Wn1);
-            rw1 = *reinterpret_cast<const float4*>(Wn1 + w16);
-            rw2 = *reinterpret_cast<const float4*>(Wn1 + 2 * w16);
-            rw3 = *reinterpret_cast<const float4*>(Wn1 + 3 * w16);
-        }
+        load_w(tn);
         __builtin_amdgcn_sched_barrier(0);
         const float* bp0 = &Ws[i * LDA + 4 * h];
         const float* bp1 = &Ws[(32 + i) * LDA + 4 * h];
@@ -405,7 +471,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
             p4 = pn; r4 = rn;
         }
-        if (tn == 0) {
+        if (last) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -422,6 +488,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
             acc0 = floatx16{};
             acc1 = floatx16{};
             par ^= 1;
+            tile = ntile;
+            mask = nmask;
         }
         t = tn;
     }
@@ -450,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 //   NW = 8 waves, <= 9 taps (<= 157 KB, one workgroup per CU): 3x3 convolutions and their data gradients.
 // Taps tap0 .. tap0+ntaps-1 of the geometry.
 constexpr int WSTAT_TAPS4 = 4, WSTAT_TAPS8 = 9;
-template <int ACT, bool HAS_T, int NW>
+template <int ACT, bool HAS_T, int NW, bool PM>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kernel(
     ConvGeom g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
@@ -481,7 +549,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
         }
     }
     const int ntiles = (g.rows_total + BMT - 1) / BMT;
-    const int nsteps = ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * ntaps;
     const RowDecoder dec(g);
     float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
     const float b0 = bias ? bias[nb * 64 + i] : 0.f;
@@ -491,14 +558,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
     RowInfo ri;
     float4 ra[8];
     bool ok_next = false;
-    int ltile = blockIdx.x, par = 0;
-    auto rows_of_tile = [&](int tile, int* op) {                   // op: this wave's 32 output pixels
+    int par = 0;
+    auto rows_of_tile = [&](int tile, const TileInfo& ti, int* op) {      // op: this wave's 32 output pixels
         const int r = tile * BMT + 32 * w + i;                     // this lane's row
         int opx = -1;
-        dec.decode<1>(r, 0, [&](int, int n, int y, int x) {
+        auto set = [&](int, int n, int y, int x) {
             ri = make_row(g, r, n, y, x);
             if (r < g.rows_total) opx = (n * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
-        });
+        };
+        if (PM) dec.decode_pm<1>(g.pm_nimg, r, 0, set);
+        else dec.decode<1>(r, 0, set);
         if (h == 0) op[i] = opx;
     };
     auto load_frag = [&](int t) {                                  // raw loads: fold / zeroing applied when consumed
@@ -509,22 +578,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ra[kk] = *reinterpret_cast<const float4*>(p + 8 * kk);
     };
-    rows_of_tile(ltile, opix + w * 32);
-    load_frag(0);
+    // one software pipeline over the workgroup's (tile, valid tap) steps; no block barrier inside
+    int tile = blockIdx.x;
+    TileInfo ti = tile_info<PM>(g, tile * BMT, BMT, tap0, ntaps);
+    unsigned mask = ti.mask;
+    int t = first_tap(mask);
+    rows_of_tile(tile, ti, opix + w * 32);
+    load_frag(t);
     floatx16 acc0 = {}, acc1 = {};
-    int t = 0;
-    for (int s = 0; s < nsteps; ++s) {
+    while (tile < ntiles) {
         float4 a[8];
         {
             const bool ok = ok_next;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<HAS_T>(ra[kk], ok, sc[HAS_T ? kk : 0], sh[HAS_T ? kk : 0]);
         }
-        int tn = t + 1;
-        if (tn == ntaps) {
-            tn = 0;
-            ltile += gridDim.x;
-            rows_of_tile(ltile, opix + ((par ^ 1) * NW + w) * 32);
+        const unsigned rest = taps_above(mask, t);
+        const bool last = rest == 0;                               // uniform: the tile's last valid tap
+        int tn, ntile = tile;
+        unsigned nmask = mask;
+        if (last) {
+            ntile = tile + gridDim.x;
+            ti = tile_info<PM>(g, ntile * BMT, BMT, tap0, ntaps);
+            nmask = ti.mask;
+            tn = first_tap(nmask);
+            rows_of_tile(ntile, ti, opix + ((par ^ 1) * NW + w) * 32);
+        } else {
+            tn = first_tap(rest);
         }
         load_frag(tn);
         __builtin_amdgcn_sched_barrier(0);
@@ -551,7 +631,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
             p4 = pn; r4 = rn;
         }
-        if (tn == 0) {
+        if (last) {
             const int* op_w = opix + (par * NW + w) * 32;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -568,6 +648,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
             acc0 = floatx16{};
             acc1 = floatx16{};
             par ^= 1;
+            tile = ntile;
+            mask = nmask;
         }
         t = tn;
     }
@@ -591,40 +673,43 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
     }
 }
 
-template <int ACT, bool HAS_T, int NW>
+template <int ACT, bool HAS_T, int NW, bool PM>
 static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, const float* bias, const float* a_scale,
                         const float* a_shift, float* out, float* stats_part, int stats_rows, int n_col_blocks,
                         int tap0, int ntaps, hipStream_t st) {
     const size_t lds = (size_t)ntaps * 64 * LDA * sizeof(float) + 2 * NW * 32 * sizeof(int) + NW * 128 * sizeof(float);
     static const bool opted = [] {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW>,
+        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         return true;
     }();
     (void)opted;
     const int ntiles = (g.rows_total + 32 * NW - 1) / (32 * NW);
-    const int cap = NW == 4 ? 512 : 256;                           // resident workgroups
-    const dim3 grid(ntiles < cap ? ntiles : cap, n_col_blocks);
-    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias, a_scale,
-                       a_shift, out, stats_part, stats_rows, tap0, ntaps);
+    // resident workgroups: two (NW = 4) or one (NW = 8) per CU
+    static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM>, 64 * NW,
+                                           NW == 4 ? 512 : 256);
+    const int cap_use = cap < (NW == 4 ? 512 : 256) ? cap : (NW == 4 ? 512 : 256);
+    const dim3 grid(ntiles < cap_use ? ntiles : cap_use, n_col_blocks);
+    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
+                       a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps);
     return check_launch("conv_gemm_wstat_kernel");
 }
 
-template <int ACT, bool HAS_T>
+template <int ACT, bool HAS_T, bool PM>
 static int dispatch_wstat(const ConvGeom& g, const float* A, const float* Wt, const float* bias, const float* a_scale,
                           const float* a_shift, float* out, float* stats_part, int stats_rows, int n_col_blocks,
                           hipStream_t st, bool* handled) {
     *handled = true;
     if (g.ntaps <= WSTAT_TAPS4)
-        return launch_wstat<ACT, HAS_T, 4>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, n_col_blocks, 0,
-                                           g.ntaps, st);
+        return launch_wstat<ACT, HAS_T, 4, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows,
+                                               n_col_blocks, 0, g.ntaps, st);
     // 8 waves, one workgroup per CU: worth its 157 KB weight fill from a few tiles per workgroup on.  (Splitting a
     // 16-tap data gradient into two accumulating 8-tap launches was measured: no gain, the read-modify-write of the
     // output eats what the barriers cost.)
     if (g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 200 * 256)
-        return launch_wstat<ACT, HAS_T, 8>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, n_col_blocks, 0,
-                                           g.ntaps, st);
+        return launch_wstat<ACT, HAS_T, 8, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows,
+                                               n_col_blocks, 0, g.ntaps, st);
     *handled = false;
     return 0;
 }
@@ -633,7 +718,7 @@ static int dispatch_wstat(const ConvGeom& g, const float* A, const float* Wt, co
 // part[blk][t][ci][co] = sum_r T(A[src(r,t)])[ci] * G[outpix(r)][g_col + co]
 // Same software pipeline as the forward kernel: while the 64 MFMAs of a tap run, the next tap's operand rows (or
 // the next tile's gradient rows and first tap) are in flight; LDS fragments are read four row-pairs ahead.
-template <int NT, bool HAS_T>
+template <int NT, bool HAS_T, bool PM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0, const float* __restrict__ A,
                                                             const float* __restrict__ a_scale,
                                                             const float* __restrict__ a_shift,
@@ -664,9 +749,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
     RowInfo ri[8];
     float4 rg[8], ra[8];
     bool ok[8];
-    // rows of a tile: operand row info + the tile's gradient rows (zero past the end), first tap in flight
-    auto open_tile = [&](int tile) {
-        dec.decode<8>(tile * BM + rb, 16, [&](int e, int n, int y, int x) {
+    // rows of a tile: operand row info + the tile's gradient rows (zero past the end), first valid tap in flight
+    auto open_tile = [&](int tile, const TileInfo& ti) {
+        const int tfirst = first_tap(ti.mask);
+        auto set = [&](int e, int n, int y, int x) {
             const int r = tile * BM + rb + 16 * e;
             ri[e] = make_row(g, r, n, y, x);
             const bool rv = r < g.rows_total;
@@ -674,36 +760,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
             float4 v = *reinterpret_cast<const float4*>(G + (long)op * g_pitch + g_col + 4 * q);
             v.x = rv ? v.x : 0.f; v.y = rv ? v.y : 0.f; v.z = rv ? v.z : 0.f; v.w = rv ? v.w : 0.f;
             rg[e] = v;
-        });
+        };
+        if (PM) dec.decode_pm<8>(g.pm_nimg, tile * BM + rb, 16, set);
+        else dec.decode<8>(tile * BM + rb, 16, set);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tap0, q, &ok[e]);
+        for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tap0 + tfirst, q, &ok[e]);
     };
-    open_tile(blockIdx.x);
+    TileInfo ti = tile_info<PM>(g, (int)blockIdx.x * BM, BM, tap0, NT);
+    unsigned mask = ti.mask;
+    open_tile(blockIdx.x, ti);
+    bool g_pending = true;                 // uniform: the tile's gradient rows still sit in registers
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        ti = tile_info<PM>(g, (tile + (int)gridDim.x) * BM, BM, tap0, NT);
+        const unsigned nmask = ti.mask;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if (!((mask >> t) & 1u)) continue;                      // uniform: tap outside the image for the whole tile
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
             if (HAS_T) {
                 sc = *reinterpret_cast<const float4*>(a_scale + g.a_col[tap0 + t] + 4 * q);
                 sh = *reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t] + 4 * q);
             }
             __syncthreads();
-            if (t == 0) {
+            if (g_pending) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     *reinterpret_cast<float4*>(&Gs[(rb + 16 * e) * 64 + 4 * q]) = rg[e];
                     dbs.x += rg[e].x; dbs.y += rg[e].y; dbs.z += rg[e].z; dbs.w += rg[e].w;
                 }
+                g_pending = false;
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 *reinterpret_cast<float4*>(&As[(rb + 16 * e) * 64 + 4 * q]) = transform_a<HAS_T>(ra[e], ok[e], sc, sh);
             __syncthreads();
-            if (t + 1 < NT) {
+            const unsigned rest = taps_above(mask, t);
+            if (rest) {
+                const int tn = first_tap(rest);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tap0 + t + 1, q, &ok[e]);
+                for (int e = 0; e < 8; ++e) ra[e] = load_a(g, A, ri[e], tap0 + tn, q, &ok[e]);
             } else {
-                open_tile(tile + gridDim.x);        // past the last tile every row is invalid: element 0 is read
+                open_tile(tile + gridDim.x, ti);                   // past the last tile every row is invalid: element 0
+                g_pending = true;
             }
             __builtin_amdgcn_sched_barrier(0);
             const float* ap = &As[h * 64 + 32 * ci_h + i];
@@ -727,6 +825,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
                 a0 = n0; a1 = n1; a2 = n2; a3 = n3; g0 = m0; g1 = m1; g2 = m2; g3 = m3;
             }
         }
+        mask = nmask;
     }
     float* pb = part + (long)blockIdx.x * NT * 4096;
 #pragma unroll
@@ -834,6 +933,9 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
     g.Ho = c->Ho; g.Wo = c->Wo; g.oys = c->oys; g.oxs = c->oxs; g.oy0 = c->oy0; g.ox0 = c->ox0; g.ntaps = c->ntaps;
     g.a_pitch = c->a_pitch; g.o_pitch = c->o_pitch; g.w_pitch = c->w_pitch;
     g.w_nblk_stride = c->w_nblk_stride;
+    // pixel-major only pays (and only keeps its tiles at one grid position) from a tile's worth of images on
+    const int npix = c->Hg * c->Wg;
+    g.pm_nimg = (c->pixel_major && npix > 0 && c->rows_total / npix >= 64) ? c->rows_total / npix : 0;
     for (int t = 0; t < 32; ++t) { g.dy[t] = c->dy[t]; g.dx[t] = c->dx[t]; g.a_col[t] = c->a_col[t]; g.w_off[t] = c->w_off[t]; }
     return g;
 }
@@ -868,36 +970,37 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     if (g.rows_total == 0) return 0;
     dim3 grid(gemm_grid(g.rows_total, n_col_blocks), n_col_blocks);
     hipStream_t st = (hipStream_t)stream;
+    const bool pm = g.pm_nimg > 0;
+    CMVAE_REQUIRE(!pm || act == 0, "cmvae_conv_gemm: pixel-major launches support act = 0 only");
     {   // weight-stationary, barrier-free kernel wherever the launch's weight tiles fit LDS
         bool handled = false;
         int e = 0;
         const int srows = (int)grid.x;
-#define CMVAE_WSTAT(ACT)                                                                                              \
-        e = a_scale ? dispatch_wstat<ACT, true>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, srows, n_col_blocks, st, &handled) \
-                    : dispatch_wstat<ACT, false>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, srows, n_col_blocks, st, &handled)
-        switch (act) {
-            case 0: CMVAE_WSTAT(0); break;
-            case 1: CMVAE_WSTAT(1); break;
-            default: CMVAE_WSTAT(2); break;
+#define CMVAE_WSTAT(ACT, PM)                                                                                          \
+        e = a_scale ? dispatch_wstat<ACT, true, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, srows, n_col_blocks, st, &handled) \
+                    : dispatch_wstat<ACT, false, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, srows, n_col_blocks, st, &handled)
+        if (pm) { CMVAE_WSTAT(0, true); }
+        else switch (act) {
+            case 0: CMVAE_WSTAT(0, false); break;
+            case 1: CMVAE_WSTAT(1, false); break;
+            default: CMVAE_WSTAT(2, false); break;
         }
 #undef CMVAE_WSTAT
         if (handled || e) return e;
     }
     if (!a_scale) {          // no folded BatchNorm: operand fragments straight from global memory
-        switch (act) {
-            case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
-            case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
-            default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
+        if (pm) hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part);
+        else switch (act) {
+            case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
+            case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
+            default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
         }
         return check_launch("conv_gemm_direct_kernel");
     }
+    CMVAE_REQUIRE(!pm, "cmvae_conv_gemm: a pixel-major launch with a folded BatchNorm needs <= %d taps", WSTAT_TAPS8);
 #define CMVAE_LAUNCH_GEMM(ACT)                                                                                  \
-    if (a_scale)                                                                                                \
-        hipLaunchKernelGGL((conv_gemm_kernel<ACT, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, \
-                           a_shift, out, stats_part);                                                           \
-    else                                                                                                        \
-        hipLaunchKernelGGL((conv_gemm_kernel<ACT, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale, \
-                           a_shift, out, stats_part)
+    hipLaunchKernelGGL((conv_gemm_kernel<ACT, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, a_scale,   \
+                       a_shift, out, stats_part)
     switch (act) {
         case 0: CMVAE_LAUNCH_GEMM(0); break;
         case 1: CMVAE_LAUNCH_GEMM(1); break;
@@ -935,12 +1038,20 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
         const int nz = nz_all > 1 ? nz_all : 1;
         float* dbp = (db && t0 == 0) ? db_part : nullptr;
         const dim3 grid(nblk, ny, nz);
+        const bool pm = g.pm_nimg > 0;
+#define CMVAE_WGRAD(NT, HAS_T, PM) \
+        hipLaunchKernelGGL((conv_wgrad_kernel<NT, HAS_T, PM>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp)
+#define CMVAE_WGRAD_NT(NT)                                                     \
+        if (a_scale) { if (pm) CMVAE_WGRAD(NT, true, true); else CMVAE_WGRAD(NT, true, false); } \
+        else { if (pm) CMVAE_WGRAD(NT, false, true); else CMVAE_WGRAD(NT, false, false); }
         switch (nt) {
-            case 1: if (a_scale) hipLaunchKernelGGL((conv_wgrad_kernel<1, true>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); else hipLaunchKernelGGL((conv_wgrad_kernel<1, false>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            case 2: if (a_scale) hipLaunchKernelGGL((conv_wgrad_kernel<2, true>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); else hipLaunchKernelGGL((conv_wgrad_kernel<2, false>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            case 3: if (a_scale) hipLaunchKernelGGL((conv_wgrad_kernel<3, true>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); else hipLaunchKernelGGL((conv_wgrad_kernel<3, false>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
-            default: if (a_scale) hipLaunchKernelGGL((conv_wgrad_kernel<4, true>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); else hipLaunchKernelGGL((conv_wgrad_kernel<4, false>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp); break;
+            case 1: CMVAE_WGRAD_NT(1) break;
+            case 2: CMVAE_WGRAD_NT(2) break;
+            case 3: CMVAE_WGRAD_NT(3) break;
+            default: CMVAE_WGRAD_NT(4) break;
         }
+#undef CMVAE_WGRAD_NT
+#undef CMVAE_WGRAD
         if (int e = check_launch("conv_wgrad_kernel")) return e;
         for (int t = 0; t < nt * nz; ++t) o.tap_off[t] = tap_off_host[t0 + t];
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nt * 64 + 1, ny, nz), dim3(1024), 0, st, part, nblk, nt, o, dW,
@@ -987,9 +1098,9 @@ static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const
     dim3 grid(gemm_grid(g.rows_total, ncb), ncb);
     float* nostats = nullptr;
     switch (act) {
-        case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
-        case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
-        default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
+        case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
+        case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
+        default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
     }
     return check_launch("conv_gemm_kernel (linear)");
 }

@@ -18,6 +18,12 @@ from ._lib import lib, check
 
 _p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
 _LAYERS = ((4, 2), (3, 4), (4, 7))          # (kernel, input size) of the three 64->64 transposed convs
+# rows of the decoder GEMMs enumerate (y, x, image): whole tiles skip the taps that fall outside the image (14 % of
+# the multiply-adds of the 7x7 -> 14x14 layer, 31 % / 44 % of the two smaller ones would multiply zero padding).
+# Measured on the layer-3 launches: forward phase 575 -> 512 us, weight gradient 635 -> 600 us, data gradient
+# 2.34 -> 2.32 ms (its 16 gathered row sets per tile no longer overlap inside a tile: what the skipped taps save goes
+# into memory traffic).
+PIXEL_MAJOR = True
 TAPS = None                                 # tests set this to a dict: receives the activations and folds of a forward
 
 
@@ -87,7 +93,7 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
     Ho = conv.convT_out(Hi, k)
     y = torch.empty(n * Ho * Ho, 64, device=x.device)
     wprep = weight.detach().permute(2, 3, 1, 0).contiguous()                 # [ky][kx][co][ci]: all k*k taps
-    phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px) for py in (0, 1) for px in (0, 1)]
+    phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=PIXEL_MAJOR) for py in (0, 1) for px in (0, 1)]
     part = None
     if want_stats:
         grids = [conv.gemm_grid(g.rows_total, 1) for g, _ in phases]
@@ -178,12 +184,12 @@ class _DecoderBCE(torch.autograd.Function):
             first = True
             for py in (0, 1):
                 for px in (0, 1):
-                    g, tap_idx = conv.geom_convT_phase(n, Hi, Hi, k, py, px)
+                    g, tap_idx = conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=PIXEL_MAJOR)
                     conv.conv_wgrad(g, x_in, dy, dW, tap_idx, s_ci=64 * k * k, s_co=k * k, db=db,
                                     accumulate_db=not first, a_scale=sc, a_shift=sh)
                     first = False
             grads_w[li], grads_b[li] = dW, db
-            gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k)
+            gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=PIXEL_MAJOR)
             wtd = ws[li].detach().permute(2, 3, 0, 1).contiguous()   # [ky][kx][ci][co]
             d_in = torch.empty(n * Hi * Hi, 64, device=dev)
             conv.conv_gemm(gd, dy, wtd, d_in)

@@ -166,6 +166,11 @@ typedef struct cmvae_conv_geom {
     int32_t a_pitch, o_pitch, w_pitch;
     int64_t w_nblk_stride;
     int32_t dy[32], dx[32], a_col[32], w_off[32];
+    /* != 0: rows enumerate (y, x, image) — r = (y*Wg + x)*n_images + image — instead of (image, y, x).  Results are the
+     * same sums; a tile of rows then sits at ONE grid position, so taps outside the image are skipped for the whole
+     * tile instead of multiplying zero padding (the stride-2 transposed convs of the decoder and their gradients).
+     * act must be 0 for such launches.                                                                              */
+    int32_t pixel_major;
 } cmvae_conv_geom;
 
 /* act: 0 none, 1 ReLU, 2 ELU.  stats_part (optional, n_col_blocks == 1): per-block partial

@@ -74,8 +74,12 @@ def em_elementwise_check(oracle, ex_g, ex_o, idx, slack=2.0, verbose=True):
     EM on unclustered latents amplifies fp32 rounding: the oracle's own fp32 run sits up to 9e-3 (element-wise, floor
     1 % of max|mu|) from its fp64 run at the Mini-ImageNet shape, so a fixed element-wise relative tolerance against
     the fp32 oracle would test rounding luck.  Instead each implementation is compared with the fp64 EM run ON ITS
-    OWN latents (the latents themselves are compared separately, at 1e-4): the HIP result must be as close to its
-    exact answer as the fp32 oracle is to its own (x slack), plus RTOL of the tensor's RMS."""
+    OWN latents (the latents themselves are compared separately, at 1e-4): for every component that owns at least
+    one latent (N_k = pi_k N >= 1) the HIP result must be as close to its exact answer as the fp32 oracle is to its
+    own (x slack), plus RTOL of the tensor's RMS.  A dying component (N_k < 1) is the weighted mean of a handful of
+    outliers whose log-likelihoods are ~ -200: one fp32 ulp there (1.5e-5) is already a 1.5e-5 relative error of
+    each weight, so its mean carries an error of that times the outliers' spread in ANY fp32 implementation; those
+    components are held to 10 x RTOL of the RMS."""
     from oracle.gmvae_oracle import OracleGMVAE
     P64 = {k: (v.detach().double() if v.is_floating_point() else v) for k, v in oracle.P.items()}
     o64 = OracleGMVAE(P64, oracle.variant, input_shape=oracle.input_shape, unsupervised_em_iters=oracle.unsup_iters,
@@ -84,12 +88,18 @@ def em_elementwise_check(oracle, ex_g, ex_o, idx, slack=2.0, verbose=True):
     with torch.no_grad():
         pi_o64, mu_o64, _ = o64.unsup_prior(ex_o['q_z'].detach().double(), idx)
         pi_g64, mu_g64, _ = o64.unsup_prior(ex_g['q_z'].detach().cpu().double(), idx)
+    N = ex_o['q_z'].shape[1]
+    live = (pi_o64 * N >= 1.0) & (pi_g64 * N >= 1.0)                       # [B,K]
     for name, g_t, g64, o_t, o64_t in (('mu_k', ex_g['mu_k'], mu_g64, ex_o['mu_k'], mu_o64),
                                        ('pi_k', ex_g['pi_k'], pi_g64, ex_o['pi_k'], pi_o64)):
-        e_gpu = float((g_t.detach().cpu().double() - g64).abs().max())
-        e_ref = float((o_t.detach().double() - o64_t).abs().max())
+        d_gpu = (g_t.detach().cpu().double() - g64).abs()
+        d_ref = (o_t.detach().double() - o64_t).abs()
+        m = live if d_gpu.dim() == 2 else live[:, :, None].expand_as(d_gpu)
         rms = float(o64_t.pow(2).mean().sqrt())
+        e_gpu, e_ref = float(d_gpu[m].max()), float(d_ref[m].max())
+        e_dying = float(d_gpu[~m].max()) if bool((~m).any()) else 0.0
         if verbose:
-            print('  %s element-wise: |gpu - fp64(gpu latents)| %.2e   |oracle32 - fp64| %.2e   rms %.3f'
-                  % (name, e_gpu, e_ref, rms))
+            print('  %s element-wise: |gpu - fp64(gpu latents)| %.2e   |oracle32 - fp64| %.2e   rms %.3f   dying '
+                  'components (%d): %.2e' % (name, e_gpu, e_ref, rms, int((~live).sum()), e_dying))
         assert e_gpu <= slack * e_ref + RTOL * rms, '%s: %.3e vs %.3e (rms %.3f)' % (name, e_gpu, e_ref, rms)
+        assert e_dying <= 10 * RTOL * rms, '%s of dying components: %.3e (rms %.3f)' % (name, e_dying, rms)

@@ -52,9 +52,14 @@ def test_conv3x3_fwd_dgrad_wgrad(device, n, H, W):
     assert rel_err(db, b.grad) < TOL
 
 
-@pytest.mark.parametrize('n,Hi,k', [(6, 2, 4), (5, 4, 3), (3, 7, 4), (70, 7, 4)])
-def test_convT_phases_with_bn_fold(device, n, Hi, k):
-    """Transposed conv over relu(bn(x)) folded into the operand load; dgrad; wgrad."""
+@pytest.mark.parametrize('n,Hi,k,pm', [(6, 2, 4, False), (5, 4, 3, False), (3, 7, 4, False), (70, 7, 4, False),
+                                          (6, 2, 4, True), (5, 4, 3, True), (70, 7, 4, True), (256, 7, 4, True),
+                                          (300, 4, 3, True), (641, 2, 4, True), (200, 7, 4, True)])
+def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
+    """Transposed conv over relu(bn(x)) folded into the operand load; dgrad; wgrad.  pm: pixel-major row order
+    (rows enumerate (y, x, image); tiles that sit at one grid position skip the taps outside the image) — image
+    counts that are multiples of the 128-row tile, not multiples of it (tiles spanning two grid positions) and
+    smaller than it."""
     from cmvae_amd import conv
     g = torch.Generator().manual_seed(k + Hi)
     x = torch.randn(n, 64, Hi, Hi, generator=g)
@@ -78,7 +83,7 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k):
     first = True
     for py in (0, 1):
         for px in (0, 1):
-            geom, tap_idx = conv.geom_convT_phase(n, Hi, Hi, k, py, px)
+            geom, tap_idx = conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=pm)
             wp = wprep
             part = conv.conv_gemm(geom, xd, wp, out, bias=bd, a_scale=scd, a_shift=shd, stats=True)
             ssum += part.sum(0).cpu()
@@ -90,11 +95,28 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k):
     assert rel_err(dW, w.grad) < TOL
     assert rel_err(db, b.grad) < TOL
     # data gradient wrt a (the post-activation input)
-    gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k)
+    gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=pm)
     wtd = w.detach().permute(2, 3, 0, 1).contiguous().to(device)      # [ky][kx][ci][co]
     da = torch.empty(n * Hi * Hi, 64, device=device)
     conv.conv_gemm(gd, gyd, wtd, da)
     assert rel_err(from_nhwc(da.cpu(), n, Hi, Hi), a.grad) < TOL
+    if pm:
+        # the same per-row sums in the same tap order: forward and data gradient agree bit for bit with the
+        # image-major launches (also without a folded BatchNorm, as in the decoder's first layer)
+        for fold in (True, False):
+            outs = []
+            for flag in (False, True):
+                o = torch.full((n * Ho * Ho, 64), float('nan'), device=device)
+                for py in (0, 1):
+                    for px in (0, 1):
+                        geom, _ = conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=flag)
+                        conv.conv_gemm(geom, xd, wprep, o, bias=bd, a_scale=scd if fold else None,
+                                       a_shift=shd if fold else None)
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1])
+        da2 = torch.empty_like(da)
+        conv.conv_gemm(conv.geom_convT_dgrad(n, Hi, Hi, k)[0], gyd, wtd, da2)
+        assert torch.equal(da, da2)
 
 
 @pytest.mark.parametrize('rows,K,N,act', [(300, 128, 256, 2), (1000, 256, 256, 1), (77, 256, 128, 0),
