@@ -335,6 +335,8 @@ def main():
     ap.add_argument('--config', choices=sorted(CONFIGS), default='o20')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-calls', type=int, default=10)
+    ap.add_argument('--eval-streams', type=int, default=4,
+                    help='HIP streams the independent prediction calls are dealt to, as Trainer.eval does (1 = sequential)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -433,29 +435,37 @@ def main():
         plans = [(cfg['sweep_call'], 'eval_episodes_per_s', max(1, cfg['sweep_episodes'] // cfg['sweep_call']))]
     else:
         plans = [(Bl, 'eval_episodes_per_s', args.eval_calls), (32, 'eval_episodes_per_s_batch32', args.eval_calls)]
+    from cmvae_amd.pipeline import PredictionPipeline
     for B_eval, key, calls in plans:
-        rates = {}
-        for shot in (1, 5):
-            if calls <= 0:
+        for n_streams, suffix in ((args.eval_streams, ''), (1, '_single_stream')):
+            if n_streams == 1 and args.eval_streams == 1 and suffix:
                 continue
-            tr, te = way * shot, way * QUERY
-            X = synth_batch(cfg, B_eval, tr + te, device, 200 + shot)
-            Xtr, Xte = X[:, :tr].contiguous(), X[:, tr:].contiguous()
-            ytr = torch.arange(way, device=device).repeat_interleave(shot)[None].repeat(B_eval, 1)
-            for _ in range(2):
-                model.prediction(Xtr, ytr, Xte)
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(calls):
-                model.prediction(Xtr, ytr, Xte)
-            barrier()
-            torch.cuda.synchronize()
-            edt = max_over_ranks(time.perf_counter() - t0)
-            rates['%dshot' % shot] = round(B_eval * world * calls / edt, 2)
-            note('eval B=%d %d-shot done' % (B_eval, shot))
-            del X, Xtr, Xte
-        eval_rates[key] = rates
+            rates = {}
+            for shot in (1, 5):
+                if calls <= 0:
+                    continue
+                tr, te = way * shot, way * QUERY
+                X = synth_batch(cfg, B_eval, tr + te, device, 200 + shot)
+                Xtr, Xte = X[:, :tr].contiguous(), X[:, tr:].contiguous()
+                ytr = torch.arange(way, device=device).repeat_interleave(shot)[None].repeat(B_eval, 1)
+                pipe = PredictionPipeline(model, n_streams)       # as Trainer.eval issues its calls
+                ncall = calls * (2 if n_streams > 1 else 1)
+                for _ in range(2 * n_streams):
+                    pipe.submit(Xtr, ytr, Xte)
+                pipe.results()
+                barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(ncall):
+                    pipe.submit(Xtr, ytr, Xte)
+                pipe.results()
+                barrier()
+                torch.cuda.synchronize()
+                edt = max_over_ranks(time.perf_counter() - t0)
+                rates['%dshot' % shot] = round(B_eval * world * ncall / edt, 2)
+                note('eval B=%d %d-shot, %d stream(s) done' % (B_eval, shot, n_streams))
+                del X, Xtr, Xte
+            eval_rates[key + suffix] = rates
     out.update(eval_rates)
     if cfg.get('eval_only'):
         r = eval_rates['eval_episodes_per_s']

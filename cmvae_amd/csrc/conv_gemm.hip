@@ -707,7 +707,10 @@ static int dispatch_wstat(const ConvGeom& g, const float* A, const float* Wt, co
     // 8 waves, one workgroup per CU: worth its 157 KB weight fill from a few tiles per workgroup on.  (Splitting a
     // 16-tap data gradient into two accumulating 8-tap launches was measured: no gain, the read-modify-write of the
     // output eats what the barriers cost.)
-    if (g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 200 * 256)
+    // (below three 256-row tiles per workgroup its single round of 256 workgroups is mostly tail: the few-shot
+    // evaluation's second encoder layer, 78400 rows = 306 tiles, ran 125 us here against the direct kernel's 128-row
+    // tiles on three workgroups per CU)
+    if (g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256)
         return launch_wstat<ACT, HAS_T, 8, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows,
                                                n_col_blocks, 0, g.ntaps, st);
     *handled = false;

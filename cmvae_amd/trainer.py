@@ -23,6 +23,7 @@ from . import dist as cdist
 from .data import EpisodeData, TrainStream
 from .linear import FlatAdam
 from .model import OmniglotGMVAE, FeatureGMVAE
+from .pipeline import PredictionPipeline
 
 # (h_lambda, h_c, a_lambda) and the shots validated after every epoch, per variant
 # (omniglot/trainer.py:74,129-130; mimgnet/trainer.py:67,118; celeba/trainer.py:67,118)
@@ -177,11 +178,16 @@ class Trainer(object):
         if eb % self.world:
             raise ValueError('eval batch size %d is not divisible by %d ranks' % (eb, self.world))
         sl = cdist.shard_slice(eb, self.rank, self.world)
+        # the calls are independent: their kernel chains overlap on a few HIP streams (cmvae_amd/pipeline.py)
+        pipe = PredictionPipeline(self.model, getattr(a, 'eval_streams', None) or 4)
+        targets = []
         for _ in range(max(1, -(-a.eval_episodes // eb))):
             X_tr, y_tr, X_te, y_te = self.data.generate_test_episode(way=a.way, shot=shot, query=a.query,
                                                                      n_episodes=eb, test=test)
-            y_pred = self.model.prediction(X_tr[sl].contiguous(), y_tr[sl].contiguous(), X_te[sl].contiguous())
-            accs.append(torch.eq(y_pred, y_te[sl]).float().mean(-1))
+            pipe.submit(X_tr[sl].contiguous(), y_tr[sl].contiguous(), X_te[sl].contiguous())
+            targets.append(y_te[sl])
+        for y_pred, y_te in zip(pipe.results(), targets):
+            accs.append(torch.eq(y_pred, y_te).float().mean(-1))
         acc = torch.cat(accs)                                          # one device->host copy per eval
         acc = cdist.gather_episode_values(acc, eb // self.world)
         acc = acc.cpu().numpy().astype(np.float64)[:a.eval_episodes]

@@ -84,3 +84,55 @@ def test_cli_entry_point_in_a_fresh_process(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert '5shot Final Test Accuracy' in r.stdout
     assert os.path.exists(str(tmp_path / 'cli' / 'train_log.jsonl'))
+
+
+def test_prediction_pipeline_equals_sequential_calls(device):
+    """Independent few-shot calls dealt to several HIP streams (cmvae_amd/pipeline.py, what Trainer.eval does).
+    Launched eagerly on the streams they return the labels of the sequential loop bit for bit, in submission order
+    (the noise is drawn on the host thread in call order).  Replayed from HIP graphs the noise comes from the
+    generator's graph-safe Philox state — the same distribution, another realisation than the eager loop's — so the
+    replayed runs are compared with each other: any number of streams gives the single-stream replay's labels."""
+    import torch
+    from cmvae_amd.pipeline import PredictionPipeline
+    from tests.helpers import build_pair, omniglot_batch
+    K, shot, query, M, B = 5, 1, 3, 8, 2
+    model, _ = build_pair('omniglot', K=K, M=M, iters=4, linear=False)
+    model.to(device).eval()
+    tr = K * shot
+    episodes = [omniglot_batch(B, tr + K * query, seed=40 + i).to(device) for i in range(9)]
+    y_tr = torch.arange(K, device=device).repeat_interleave(shot)[None].repeat(B, 1)
+
+    def run(n_streams, graphs):
+        torch.manual_seed(3)
+        pipe = PredictionPipeline(model, n_streams, use_graphs=graphs)
+        for X in episodes:
+            pipe.submit(X[:, :tr].contiguous(), y_tr, X[:, tr:].contiguous())
+        got = pipe.results()
+        assert pipe.results() == [] and len(got) == len(episodes)
+        return got
+
+    torch.manual_seed(3)
+    ref = [model.prediction(X[:, :tr].contiguous(), y_tr, X[:, tr:].contiguous()) for X in episodes]
+    for n_streams in (1, 3):
+        for a, b in zip(run(n_streams, False), ref):
+            assert torch.equal(a, b), n_streams
+    ref_g = run(1, True)
+    for n_streams, graphs in ((3, True), (4, None)):
+        for a, b in zip(run(n_streams, graphs), ref_g):
+            assert torch.equal(a, b), n_streams
+    # replayed and eager calls see the same inputs and weights: with the noise switched off (M large enough that the
+    # MC average decides) they need not agree label for label, but both must be valid labellings
+    assert all(int(y.min()) >= 0 and int(y.max()) < K for y in ref_g)
+    # a second shape on the same pipeline captures a second graph
+    pipe = PredictionPipeline(model, 2)
+    X5 = omniglot_batch(B, 2 * K + K * query, seed=77).to(device)
+    y5 = torch.arange(K, device=device).repeat_interleave(2)[None].repeat(B, 1)
+    for _ in range(3):
+        pipe.submit(episodes[0][:, :tr].contiguous(), y_tr, episodes[0][:, tr:].contiguous())
+        pipe.submit(X5[:, :2 * K].contiguous(), y5, X5[:, 2 * K:].contiguous())
+    out = pipe.results()
+    assert tuple(out[0].shape) == (B, K * query) and tuple(out[1].shape) == (B, K * query)
+    model.train()
+    import pytest
+    with pytest.raises(RuntimeError):
+        PredictionPipeline(model, 2)
