@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
 EM_ITERS, QUERY = 10, 15
+PMC_CONFIG = 'o20'             # which committed profiles/r*_<config>_pmc_traffic.json the roofline traffic is read from
 WAY, SAMPLE, MC, B_PER_GPU = 20, 300, 32, 4        # the default (o20) shape, for the probes under tools/
 
 CONFIGS = {
@@ -147,7 +148,8 @@ def pmc_traffic(select):
     committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes over this same
     workload, gfx950 correction applied).  PMC counters cannot be read from inside this process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s_pmc_traffic.json' % PMC_CONFIG))) or \
+        (sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json'))) if PMC_CONFIG == 'o20' else [])
     if not files:
         return None, None
     ks = json.load(open(files[-1]))['kernels']
@@ -339,6 +341,8 @@ def main():
                     help='HIP streams the independent prediction calls are dealt to, as Trainer.eval does (1 = sequential)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    global PMC_CONFIG
+    PMC_CONFIG = args.config
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))

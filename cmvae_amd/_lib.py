@@ -100,6 +100,11 @@ SIGNATURES = {
                                  c_void_p, c_size_t, c_void_p]),
     'cmvae_linear_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                  c_void_p]),
+    'cmvae_linear_mse_partials': (c_int, [c_int, c_int]),
+    'cmvae_linear_mse_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                     c_void_p, c_int, c_void_p, c_void_p]),
+    'cmvae_mse_act_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p,
+                                  c_void_p]),
     'cmvae_act_bwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     'cmvae_linear_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'cmvae_linear_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,

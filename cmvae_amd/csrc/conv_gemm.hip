@@ -348,12 +348,17 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
 // tile and loads its operand directly in MFMA fragment layout (8 x 16 B: channels 8kk + 4h .. +3), one step ahead.
 // The operand never passes through LDS: no staging stores, no A-fragment reads, one row decode per lane, and the
 // two barriers of a step only guard the 16 KB weight tile.
+// mse_target != NULL (nn.Linear launches of the feature models' last proj layer): the epilogue also accumulates the
+// squared error of the activated output against target[row / mse_M][column] — the Gaussian likelihood of
+// mimgnet/model.py:391 — into stats_part's column sums instead of the BatchNorm statistics.
 template <int ACT, bool LINEAR, bool PM>
 __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, const float* __restrict__ A,
                                                                   const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out,
-                                                                  float* __restrict__ stats_part) {
+                                                                  float* __restrict__ stats_part,
+                                                                  const float* __restrict__ mse_target, int mse_M,
+                                                                  int mse_pitch) {
     __shared__ __align__(16) float Ws[64 * LDA];
     __shared__ int opix[2][BM];
     __shared__ float red[4 * 128];
@@ -478,11 +483,19 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
                 const int op = opix[par][row];
                 if (op >= 0) {
                     const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
-                    ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
-                    ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
                     float* o = out + (long)op * g.o_pitch + nb * 64;
-                    o[i] = apply_act<ACT>(v0);
-                    o[32 + i] = apply_act<ACT>(v1);
+                    const float y0 = apply_act<ACT>(v0), y1 = apply_act<ACT>(v1);
+                    o[i] = y0;
+                    o[32 + i] = y1;
+                    if (LINEAR && mse_target) {          // uniform
+                        const float* tg = mse_target + (long)((unsigned)op / (unsigned)mse_M) * mse_pitch + nb * 64;
+                        const float e0 = y0 - tg[i], e1 = y1 - tg[32 + i];
+                        ssum0 = fmaf(e0, e0, ssum0);
+                        ssum1 = fmaf(e1, e1, ssum1);
+                    } else {
+                        ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
+                        ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
+                    }
                 }
             }
             acc0 = floatx16{};
@@ -992,11 +1005,11 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
         if (handled || e) return e;
     }
     if (!a_scale) {          // no folded BatchNorm: operand fragments straight from global memory
-        if (pm) hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part);
+        if (pm) hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part, (const float*)nullptr, 1, 0);
         else switch (act) {
-            case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
-            case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
-            default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part); break;
+            case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part, (const float*)nullptr, 1, 0); break;
+            case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part, (const float*)nullptr, 1, 0); break;
+            default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, false, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part, (const float*)nullptr, 1, 0); break;
         }
         return check_launch("conv_gemm_direct_kernel");
     }
@@ -1097,13 +1110,13 @@ static ConvGeom linear_geom(int rows, int K, int N, int a_pitch, int o_pitch) {
 }
 
 static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const float* bias, int act, int ncb,
-                       float* out, hipStream_t st) {
+                       float* out, hipStream_t st, const float* mse_target = nullptr, int mse_M = 1, int mse_pitch = 0,
+                       float* mse_part = nullptr) {
     dim3 grid(gemm_grid(g.rows_total, ncb), ncb);
-    float* nostats = nullptr;
     switch (act) {
-        case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
-        case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
-        default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, nostats); break;
+        case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, mse_part, mse_target, mse_M, mse_pitch); break;
+        case 1: hipLaunchKernelGGL((conv_gemm_direct_kernel<1, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, mse_part, mse_target, mse_M, mse_pitch); break;
+        default: hipLaunchKernelGGL((conv_gemm_direct_kernel<2, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, mse_part, mse_target, mse_M, mse_pitch); break;
     }
     return check_launch("conv_gemm_kernel (linear)");
 }
@@ -1157,6 +1170,27 @@ extern "C" int cmvae_linear_fwd(const float* X, int x_pitch, int rows, int in_f,
     if (rows == 0) return 0;
     return launch_gemm(linear_geom(rows, in_f, out_f, x_pitch, y_pitch), X, W, bias, act, out_f / 64, Y,
                        (hipStream_t)stream);
+}
+
+extern "C" int cmvae_linear_mse_partials(int rows, int out_f) {
+    cmvae::clear_stale_error();
+    if (out_f < 64) return 0;
+    return gemm_grid(rows, out_f / 64) * (out_f / 64);
+}
+
+extern "C" int cmvae_linear_mse_fwd(const float* X, int x_pitch, int rows, int in_f, int out_f, const float* W,
+                                    const float* bias, int act, const float* target, int M, float* Y, int y_pitch,
+                                    float* loss_part, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(X && W && Y && target && loss_part, "cmvae_linear_mse_fwd: NULL argument");
+    if (int e = check_linear("cmvae_linear_mse_fwd", rows, in_f, out_f)) return e;
+    CMVAE_REQUIRE(x_pitch >= in_f && x_pitch % 4 == 0 && y_pitch >= out_f && act >= 0 && act <= 2,
+                  "cmvae_linear_mse_fwd: bad pitch / act");
+    CMVAE_REQUIRE(M >= 1 && rows >= 1 && rows % M == 0, "cmvae_linear_mse_fwd: rows=%d must be a positive multiple of M=%d",
+                  rows, M);
+    CMVAE_REQUIRE((long)rows * x_pitch < (1L << 31), "cmvae_linear_mse_fwd: operand larger than 2^31 elements");
+    return launch_gemm(linear_geom(rows, in_f, out_f, x_pitch, y_pitch), X, W, bias, act, out_f / 64, Y,
+                       (hipStream_t)stream, target, M, out_f, loss_part);
 }
 
 extern "C" size_t cmvae_linear_bwd_workspace_bytes(int rows, int in_f, int out_f) {

@@ -277,6 +277,31 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__
     }
 }
 
+// dZ = act'(.) * gscale * 2 (Y - target[row / M]) from the saved post-activation Y [rows, F]: the backward of the
+// squared-error sum of the feature models (mimgnet/model.py:391) through the last proj activation
+template <int ACT>
+__global__ __launch_bounds__(256) void mse_act_bwd_kernel(const float4* __restrict__ Y, const float4* __restrict__ T,
+                                                          long n4, int f4, int M, const float* __restrict__ g_dev,
+                                                          float gmul, float4* __restrict__ dZ) {
+    const float gs = 2.f * gmul * (g_dev ? g_dev[0] : 1.f);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const long row = e / f4;
+        const int c = (int)(e - row * f4);
+        const float4 y = Y[e], t = T[(row / M) * f4 + c];
+        float4 g = make_float4(gs * (y.x - t.x), gs * (y.y - t.y), gs * (y.z - t.z), gs * (y.w - t.w)), o;
+        if (ACT == 0) {
+            o = g;
+        } else if (ACT == 1) {
+            o.x = y.x > 0.f ? g.x : 0.f; o.y = y.y > 0.f ? g.y : 0.f;
+            o.z = y.z > 0.f ? g.z : 0.f; o.w = y.w > 0.f ? g.w : 0.f;
+        } else {
+            o.x = y.x > 0.f ? g.x : g.x * (y.x + 1.f); o.y = y.y > 0.f ? g.y : g.y * (y.y + 1.f);
+            o.z = y.z > 0.f ? g.z : g.z * (y.z + 1.f); o.w = y.w > 0.f ? g.w : g.w * (y.w + 1.f);
+        }
+        dZ[e] = o;
+    }
+}
+
 // ---------------------------------------------------------------- NOTEARS-MLP tail on bulk rows
 // eps[r][j] = x[r][j] - (sum_m hid[r][32j+m] * w2[j][m] + b2[j]),  hid = elu(fc1(x)) from the Linear kernel.
 // 8 lanes x float4 cover the 32 hidden units of one (row, j).
@@ -371,6 +396,20 @@ extern "C" int cmvae_act_bwd(const float* dY, const float* Y, int64_t n, int act
         hipLaunchKernelGGL(act_bwd_kernel<2>, dim3(grid_for(n4, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float4*)dY, (const float4*)Y, n4, (float4*)dZ);
     return check_launch("act_bwd_kernel");
+}
+
+extern "C" int cmvae_mse_act_bwd(const float* Y, const float* target, int rows, int F, int M, int act,
+                                 const float* g_dev, float gmul, float* dZ, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(Y && target && dZ && rows >= 1 && F >= 4 && F % 4 == 0 && M >= 1 && rows % M == 0 && act >= 0 && act <= 2,
+                  "cmvae_mse_act_bwd: bad arguments");
+    const long n4 = (long)rows * F / 4;
+    const dim3 grid(grid_for(n4, 256));
+#define CMVAE_MSE_BWD(ACT) hipLaunchKernelGGL(mse_act_bwd_kernel<ACT>, grid, dim3(256), 0, (hipStream_t)stream, \
+        (const float4*)Y, (const float4*)target, n4, F / 4, M, g_dev, gmul, (float4*)dZ)
+    if (act == 0) CMVAE_MSE_BWD(0); else if (act == 1) CMVAE_MSE_BWD(1); else CMVAE_MSE_BWD(2);
+#undef CMVAE_MSE_BWD
+    return check_launch("mse_act_bwd_kernel");
 }
 
 extern "C" int cmvae_causal_lc_fwd(const float* x, const float* hid, const float* w2, const float* b2, int rows,

@@ -97,6 +97,57 @@ def linear(x, weight, bias=None, act=None):
     return _Linear.apply(x, weight, bias, ACT[act])
 
 
+class _LinearMSE(torch.autograd.Function):
+    """y = act(x W^T + b) and sum((y - target[row // M])^2) from the GEMM epilogue (cmvae_linear_mse_fwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, target, M):
+        _need(x, 'x'); _need(weight, 'weight'); _need(target, 'target')
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        w = weight.contiguous()
+        rows, out_f = x2.shape[0], w.shape[0]
+        t2 = target.reshape(-1, out_f).contiguous()
+        if rows == 0 or rows != t2.shape[0] * M:
+            raise RuntimeError('cmvae_amd.linear_mse: %d rows against %d targets x %d samples' % (rows, t2.shape[0], M))
+        y = torch.empty(rows, out_f, device=x2.device, dtype=torch.float32)
+        part = torch.empty(lib.cmvae_linear_mse_partials(rows, out_f), 128, device=x2.device, dtype=torch.float32)
+        check(lib.cmvae_linear_mse_fwd(_p(x2), x2.stride(0), rows, x2.shape[1], out_f, _p(w),
+                                       None if bias is None else _p(bias.contiguous()), act, _p(t2), M, _p(y),
+                                       y.stride(0), _p(part), _stream()), 'cmvae_linear_mse_fwd')
+        if TAPS is not None and act == 1:
+            TAPS.setdefault('linear_relu', []).append(y)
+        ctx.act, ctx.shape, ctx.has_bias, ctx.M = act, x.shape, bias is not None, M
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x2, w, y, t2)
+        return y.view(*x.shape[:-1], out_f), part.sum()
+
+    @staticmethod
+    def backward(ctx, dy, dloss):
+        x2, w, y, t2 = ctx.saved_tensors
+        dz = None
+        if dloss is not None:
+            dz = torch.empty_like(y)
+            check(lib.cmvae_mse_act_bwd(_p(y), _p(t2), y.shape[0], y.shape[1], ctx.M, ctx.act,
+                                        _p(dloss.reshape(1).contiguous()), 1.0, _p(dz), _stream()), 'cmvae_mse_act_bwd')
+        if dy is not None:
+            dy2 = dy.reshape(-1, w.shape[0]).contiguous()
+            d2 = act_bwd(dy2, y, ctx.act) if ctx.act else dy2
+            dz = d2 if dz is None else dz + d2
+        if dz is None:
+            dz = torch.zeros_like(y)
+        dx, dW, db = linear_bwd(x2, w, dz, ctx.needs_input_grad[0], ctx.has_bias)
+        return (None if dx is None else dx.view(ctx.shape)), dW, db, None, None, None
+
+
+def linear_mse(x, weight, bias, act, target, M):
+    """(act(x W^T + b), F.mse_loss(., target repeated M times per row, reduction='sum')) — the last proj layer of the
+    feature models with their Gaussian likelihood (mimgnet/model.py:59-66, 388-391) in one GEMM launch; the target is
+    not differentiated (it is the input features)."""
+    return _LinearMSE.apply(x, weight, bias, ACT[act], target.detach(), int(M))
+
+
 class _CausalMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, fc1_w, fc1_b, w2, b2):

@@ -37,6 +37,9 @@ def build_parser(variant):
     p.add_argument('--eval-batch-size', type=int, default=None,
                    help='episodes per prediction call during evaluation (default: --batch-size, as the reference; '
                         '32 doubles the evaluation throughput on one MI355X)')
+    p.add_argument('--dual-ascent', action='store_true',
+                   help='run the augmented-Lagrangian schedule on (h_lambda, h_c) after every epoch: the block the '
+                        'reference carries commented out (omniglot/trainer.py:171-177); off = the reference\'s live code')
     p.add_argument('--eval-streams', type=int, default=4,
                    help='HIP streams the independent prediction calls of an evaluation are dealt to (new; 1 = the '
                         'reference\'s sequential loop, same results)')

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import ops
 from .module import OmniglotEncoder, OmniglotDecoder, SAB, CausalEncoder
-from .linear import linear
+from .linear import linear, linear_mse
 from .decoder import decoder_bce, nhwc_perm, permute
 
 _LOG_NORM = -0.5 * np.log(2 * np.pi)
@@ -321,10 +321,12 @@ class FeatureGMVAE(_GMVAEBase):
         q_eps = self.causal(q_z)
         A = self.causal.get_w()
         h = torch.cat([q_z, q_eps], -1).view(-1, 2 * D)
-        for i in (0, 2, 4):
+        for i in (0, 2):
             h = linear(h, self.proj[i].weight, self.proj[i].bias, 'relu')
+        # the last proj layer and the squared error against the input features leave one GEMM launch
+        h, sq_err = linear_mse(h, self.proj[4].weight, self.proj[4].bias, 'relu', H, M)
         H_rec = h.view(B, S, M, self.input_shape)
-        rec_loss = (H_rec - H[:, :, None]).pow(2).sum() / (B * S * M)
+        rec_loss = sq_err / (B * S * M)
         kl_loss, h_augment, h = self._kl_and_h(q_z, log_q_z, q_eps, A, h_lambda, h_c, a_lambda, init_idx, extras)
         if extras is not None:
             extras.update(q_z_mean=q_mean, q_z_logvar=q_logvar)

@@ -34,6 +34,22 @@ VARIANTS = {
 }
 
 
+def dual_ascent_update(h, h_lambda, h_c, h_old, h_tol=1e-8, h_c_max=1e11):
+    """The augmented-Lagrangian schedule the reference carries commented out at the end of every epoch
+    (omniglot/trainer.py:73-74, 171-177): while the acyclicity value h stays above `h_tol`, the penalty weight h_c
+    grows tenfold whenever h failed to shrink to a quarter of its previous value (up to `h_c_max`), and the multiplier
+    takes the dual-ascent step h_lambda += h_c * h (NOTEARS).  As written in the reference the last line adds to
+    `h_augment`, a per-step loss value that the next step recomputes — inert; the multiplier update is what the
+    schedule's variables (`causal/h_lambda`, `causal/h_c` are logged) are there for.  Returns (h_lambda, h_c, h_old).
+    Off by default (`--dual-ascent`), exactly like the reference's live code."""
+    h = float(h)
+    if h > h_tol:
+        if h > h_old * 0.25 and h_c < h_c_max:
+            h_c *= 10
+        h_lambda += h_c * h
+    return h_lambda, h_c, h
+
+
 class Trainer(object):
     def __init__(self, args, variant='omniglot'):
         self.args, self.variant = args, variant
@@ -98,6 +114,7 @@ class Trainer(object):
         a, spec = self.args, VARIANTS[self.variant]
         h_lambda, h_c, a_lambda = spec['consts']
         global_epoch = global_step = 0
+        h_old = float('inf')
         best = {shot: 0.0 for shot, _ in spec['val']}
         while global_epoch * a.freq_iters < a.train_iters:
             t0 = time.perf_counter()
@@ -114,7 +131,7 @@ class Trainer(object):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             rec = {'epoch': global_epoch, 'step': global_step, 'train_episodes_per_s': a.batch_size * steps / dt,
-                   'h_lambda': h_lambda, 'h_c': h_c, 'lr': a.lr}
+                   'h_lambda': h_lambda, 'h_c': h_c, 'h': float(h.detach()), 'lr': a.lr}
             for shot, test in spec['val']:
                 mean, conf = self.eval(shot=shot, test=test)
                 rec['%dshot_acc' % shot], rec['%dshot_conf' % shot] = mean, conf
@@ -124,6 +141,8 @@ class Trainer(object):
                 if self.rank == 0:
                     print('{0}shot {1}-th EPOCH Val Accuracy: {2:.4f}, BEST Accuracy: {3:.4f}'.format(
                         shot, global_epoch, mean, best[shot]))
+            if getattr(a, 'dual_ascent', False):
+                h_lambda, h_c, h_old = dual_ascent_update(h.detach(), h_lambda, h_c, h_old)
             self._log(rec)
             global_epoch += 1
         return self.final_test()

@@ -196,6 +196,18 @@ int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, const float* a
  * 64, at most 2048.  Y = act(X W^T + bias); act: 0 none, 1 ReLU, 2 ELU.                                       */
 int cmvae_linear_fwd(const float* X, int x_pitch, int rows, int in_f, int out_f, const float* W,
                      const float* bias, int act, float* Y, int y_pitch, void* stream);
+/* The last proj layer of the feature models fused with their Gaussian likelihood (mimgnet/model.py:59-66, 388-391):
+ * Y = act(X W^T + bias) as cmvae_linear_fwd, and the squared error of Y against target[row / M, :] (target
+ * [rows / M, out_f]: the features every MC sample reconstructs) summed into loss_part
+ * [cmvae_linear_mse_partials(rows, out_f)][128] — F.mse_loss(reduction='sum') is the sum of all its entries.
+ * Backward of that sum through the activation: dZ = act'(.) * gmul * g_dev[0] * 2 (Y - target) (g_dev: device scalar,
+ * the upstream gradient of the loss sum, or NULL for 1); dZ then feeds cmvae_linear_bwd.                        */
+int cmvae_linear_mse_partials(int rows, int out_f);
+int cmvae_linear_mse_fwd(const float* X, int x_pitch, int rows, int in_f, int out_f, const float* W,
+                         const float* bias, int act, const float* target, int M, float* Y, int y_pitch,
+                         float* loss_part, void* stream);
+int cmvae_mse_act_bwd(const float* Y, const float* target, int rows, int F, int M, int act,
+                      const float* g_dev, float gmul, float* dZ, void* stream);
 /* dZ = dY * act'(.) from the saved output Y (n elements, n % 4 == 0; act 1 or 2).                         */
 int cmvae_act_bwd(const float* dY, const float* Y, int64_t n, int act, float* dZ, void* stream);
 /* dX = dZ W (skipped when dX == NULL), dW[out_f,in_f] = dZ^T X, db[out_f] = column sums of dZ (may be NULL). */

@@ -101,3 +101,18 @@ def test_cli_defaults_match_the_reference_flags():
     a = build_parser('mimgnet').parse_args(['--data-dir', 'x', '--save-dir', 'y'])
     assert (a.batch_size, a.sample_size, a.way, a.train_mc_sample_size, a.lr, a.train_iters, a.shot, a.seed) == \
         (16, 5, 5, 256, 1e-4, 100000, 1, 15)
+
+
+def test_dual_ascent_schedule():
+    """The augmented-Lagrangian schedule of omniglot/trainer.py:171-177 (commented out in the reference; offered
+    behind --dual-ascent): h_c grows tenfold while h does not shrink to a quarter, the multiplier takes h_c * h."""
+    from cmvae_amd.trainer import dual_ascent_update
+    hl, hc, ho = 0.1, 0.1, float('inf')
+    hl, hc, ho = dual_ascent_update(0.08, hl, hc, ho)              # first epoch: h_old = inf, no growth
+    assert (hc, ho) == (0.1, 0.08) and abs(hl - (0.1 + 0.1 * 0.08)) < 1e-12
+    hl2, hc2, ho2 = dual_ascent_update(0.05, hl, hc, ho)           # 0.05 > 0.25 * 0.08: penalty grows, then the step
+    assert hc2 == 1.0 and abs(hl2 - (hl + 1.0 * 0.05)) < 1e-12 and ho2 == 0.05
+    hl3, hc3, ho3 = dual_ascent_update(0.01, hl2, hc2, ho2)        # shrank below a quarter: penalty kept
+    assert hc3 == 1.0 and abs(hl3 - (hl2 + 0.01)) < 1e-12
+    assert dual_ascent_update(1e-9, 0.3, 10.0, 0.01) == (0.3, 10.0, 1e-9)     # below h_tol: nothing moves
+    assert dual_ascent_update(1.0, 0.0, 1e11, 1.0)[1] == 1e11                  # capped at h_c_max

@@ -38,6 +38,41 @@ def test_linear_fwd_bwd(rows, in_f, out_f, act):
     assert _rel(bd.grad, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize('n_t,M,in_f,out_f,act', [(40, 10, 1024, 512, 'relu'), (7, 3, 128, 64, 'elu'),
+                                                   (1, 1, 64, 128, None), (300, 10, 1280, 640, 'relu')])
+def test_linear_mse_epilogue(n_t, M, in_f, out_f, act):
+    """Last proj layer + F.mse_loss(reduction='sum') of the feature models (mimgnet/model.py:59-66, 388-391) from one
+    GEMM launch: value, the gradient of the loss alone, and loss + a use of the output together."""
+    from cmvae_amd.linear import linear_mse
+    g = torch.Generator().manual_seed(n_t * 31 + M)
+    rows = n_t * M
+    x = torch.randn(rows, in_f, generator=g)
+    W = torch.randn(out_f, in_f, generator=g) / np.sqrt(in_f)
+    b = torch.randn(out_f, generator=g) * 0.1
+    tgt = torch.randn(n_t, out_f, generator=g).abs()
+    gy = torch.randn(rows, out_f, generator=g)
+    for use_y in (False, True):
+        xr, Wr, br = (t.clone().double().requires_grad_(True) for t in (x, W, b))
+        yr = ACTS[act](F.linear(xr, Wr, br))
+        lr = F.mse_loss(yr, tgt.double().repeat_interleave(M, 0), reduction='sum')
+        (lr * 0.37 + ((yr * gy.double()).sum() if use_y else 0.)).backward()
+        xd, Wd, bd = (t.cuda().requires_grad_(True) for t in (x, W, b))
+        yd, ld = linear_mse(xd, Wd, bd, act, tgt.cuda(), M)
+        (ld * 0.37 + ((yd * gy.cuda()).sum() if use_y else 0.)).backward()
+        assert _rel(yd, yr) < 1e-5
+        assert abs(float(ld.detach()) - float(lr.detach())) < 2e-6 * abs(float(lr.detach()))
+        assert _rel(xd.grad, xr.grad) < 1e-5
+        assert _rel(Wd.grad, Wr.grad) < 2e-5
+        assert _rel(bd.grad, br.grad) < 2e-5
+
+
+def test_linear_mse_rejects_mismatched_targets():
+    from cmvae_amd.linear import linear_mse
+    x, W = torch.randn(30, 64).cuda(), torch.randn(64, 64).cuda()
+    with pytest.raises(RuntimeError):
+        linear_mse(x, W, None, 'relu', torch.randn(4, 64).cuda(), 10)
+
+
 def test_linear_batched_shape_no_bias_no_input_grad():
     from cmvae_amd.linear import linear
     x = torch.randn(4, 50, 256)
