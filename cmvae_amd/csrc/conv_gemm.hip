@@ -866,6 +866,189 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
     }
 }
 
+// ---------------------------------------------------------------------------- weight gradient, streaming variant
+// For launches whose image count is a multiple of 16.  Nothing is staged through LDS and the main loop has no
+// barrier: the contraction runs over rows, and v_mfma_f32_16x16x4_f32 takes A[m][k] / B[k][n] with k = lane >> 4, so
+// ONE 16-byte load per lane of an operand row (lane (i, kq): channels 4i..4i+3 of row kq of a 4-row group) and one of
+// the gradient row are the fragments of 16 MFMAs: component ja of the operand against component jb of the gradient
+// accumulates the (ci = 4m + ja, co = 4n + jb) sub-lattice of the 64x64 tap block.  A wave owns TWO taps (128
+// accumulators) and walks a contiguous range of chunks (16 images at one grid position, positions fastest, so the
+// shifted operand rows of neighbouring positions are re-read while still in L2); a tap outside the image at that
+// position is skipped for the whole chunk, whatever the launch's row order.  Four 4-row groups = one chunk are in
+// flight per wave (loads of chunk c+1 are issued as chunk c's groups are consumed).  The waves of a workgroup split
+// into tap pairs x row streams and add their accumulators through LDS once, at the end.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct ChunkDesc {
+    int a[2];                 // per-lane element offsets of the two taps' operand rows (group 0)
+    int go;                   // ... of the gradient row
+    int sa[2], sg;            // uniform: offset step between 4-row groups (0 for a skipped tap / dead chunk)
+    unsigned valid;           // uniform: bit u = tap u inside the image, bit 2 = chunk inside the range
+};
+
+template <bool HAS_T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, int tap0, int nt, int nimg,
+                                                                   const float* __restrict__ A,
+                                                                   const float* __restrict__ a_scale,
+                                                                   const float* __restrict__ a_shift,
+                                                                   const float* __restrict__ G, int g_pitch, int g_col,
+                                                                   float* __restrict__ part,
+                                                                   float* __restrict__ db_part) {
+    __shared__ __align__(16) float comb[2 * 128 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kq = lane >> 4;
+    tap0 += nt * blockIdx.z;
+    g_col += 64 * blockIdx.y;
+    {
+        const long slot = (long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x;
+        part += slot * nt * 4096;
+        if (db_part) db_part += slot * 64;
+        if (blockIdx.z != 0) db_part = nullptr;
+    }
+    const bool split = nt > 2;                                   // two tap pairs x two row streams, else four row streams
+    const int tp = split ? (w & 1) : 0;
+    const int p = split ? (w >> 1) : w;
+    const int P = split ? 2 : 4;
+    const int npix = g.Hg * g.Wg;
+    const int nchunks = (nimg / 16) * npix;
+    const int nstreams = (int)gridDim.x * P, sid = (int)blockIdx.x * P + p;
+    const int c_begin = (int)((long)nchunks * sid / nstreams), c_end = (int)((long)nchunks * (sid + 1) / nstreams);
+    const int t_u[2] = {2 * tp, 2 * tp + 1};                     // the wave's taps within the launch group
+    const int img_a = g.Hi * g.Wi * g.a_pitch, img_g = g.Ho * g.Wo * g_pitch;
+
+    float4 sc[2], sh[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        sc[u] = make_float4(1.f, 1.f, 1.f, 1.f); sh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (HAS_T && t_u[u] < nt) {
+            sc[u] = *reinterpret_cast<const float4*>(a_scale + g.a_col[tap0 + t_u[u]] + 4 * i);
+            sh[u] = *reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t_u[u]] + 4 * i);
+        }
+    }
+    auto describe = [&](int ib, int y, int x, bool live) {
+        ChunkDesc d;
+        const int img = ib * 16 + kq;
+        const int ys = y * g.sy, xs = x * g.sx;
+        d.valid = live ? 4u : 0u;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bool in = false;
+            int off = 0;
+            if (t_u[u] < nt) {
+                const int t = tap0 + t_u[u];
+                const int dy = g.dy[t], dx = g.dx[t];
+                in = live & ((unsigned)(ys + dy) < (unsigned)g.Hi) & ((unsigned)(xs + dx) < (unsigned)g.Wi);
+                off = ((img * g.Hi + ys + dy) * g.Wi + xs + dx) * g.a_pitch + g.a_col[t];
+            }
+            d.a[u] = (in ? off : 0) + 4 * i;
+            d.sa[u] = in ? 4 * img_a : 0;
+            d.valid |= in ? (1u << u) : 0u;
+        }
+        const int op = (img * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
+        d.go = (live ? op * g_pitch + g_col : 0) + 4 * i;
+        d.sg = live ? 4 * img_g : 0;
+#if CMVAE_ABLATE == 7      // every operand load hits the same 256 bytes: the MFMA-side ceiling of this loop
+        d.a[0] = d.a[1] = d.go = 4 * i; d.sa[0] = d.sa[1] = d.sg = 0;
+#endif
+        return d;
+    };
+
+    floatx4 acc[2][16];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[u][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool want_db = db_part != nullptr && tp == 0;
+
+    float4 ra[4][2], rg[4];
+    auto issue = [&](int slot, const ChunkDesc& d, int s) {
+        ra[slot][0] = *reinterpret_cast<const float4*>(A + d.a[0] + s * d.sa[0]);
+        ra[slot][1] = *reinterpret_cast<const float4*>(A + d.a[1] + s * d.sa[1]);
+        rg[slot] = *reinterpret_cast<const float4*>(G + d.go + s * d.sg);
+    };
+    auto consume = [&](int slot, unsigned valid) {
+        const float4 gv = rg[slot];
+        if (want_db && (valid & 4u)) { dbs.x += gv.x; dbs.y += gv.y; dbs.z += gv.z; dbs.w += gv.w; }
+        const float gb[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!((valid >> u) & 1u)) continue;                  // uniform
+            const float4 a = transform_a<HAS_T>(ra[slot][u], true, sc[u], sh[u]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+                    acc[u][ja * 4 + jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ja], gb[jb], acc[u][ja * 4 + jb], 0, 0, 0);
+        }
+    };
+
+    int c = c_begin;
+    int ib = c / npix;
+    int y, x;
+    { const int pix = c - ib * npix; y = pix / g.Wg; x = pix - y * g.Wg; }
+    ChunkDesc cur = describe(ib, y, x, c < c_end);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) issue(s, cur, s);
+    for (; c < c_end; ++c) {
+        if (++x == g.Wg) { x = 0; if (++y == g.Hg) { y = 0; ++ib; } }
+        const ChunkDesc nxt = describe(ib, y, x, c + 1 < c_end);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            consume(s, cur.valid);
+            issue(s, nxt, s);
+        }
+        cur = nxt;
+    }
+
+    // add the row streams of a tap pair (wave p == 0 keeps the sum): lane-major LDS image of the 128 accumulators
+    float* cb = comb + tp * 8192 + lane;
+    for (int k = 1; k < P; ++k) {
+        if (p == k) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 64; ++r) cb[(u * 64 + r) * 64] = acc[u][r >> 2][r & 3];
+        }
+        __syncthreads();
+        if (p == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 64; ++r) acc[u][r >> 2][r & 3] += cb[(u * 64 + r) * 64];
+        }
+        __syncthreads();
+    }
+    if (db_part) {
+        dbs.x += __shfl_xor(dbs.x, 16); dbs.y += __shfl_xor(dbs.y, 16); dbs.z += __shfl_xor(dbs.z, 16); dbs.w += __shfl_xor(dbs.w, 16);
+        dbs.x += __shfl_xor(dbs.x, 32); dbs.y += __shfl_xor(dbs.y, 32); dbs.z += __shfl_xor(dbs.z, 32); dbs.w += __shfl_xor(dbs.w, 32);
+        if (tp == 0 && kq == 0) *reinterpret_cast<float4*>(&comb[p * 64 + 4 * i]) = dbs;
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+            for (int k = 0; k < P; ++k) sum += comb[k * 64 + tid];
+            db_part[(long)blockIdx.x * 64 + tid] = sum;
+        }
+    }
+    if (p == 0) {
+        float* pb = part + (long)blockIdx.x * nt * 4096;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (t_u[u] >= nt) continue;
+#pragma unroll
+            for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = 16 * kq + 4 * r + ja;
+                    *reinterpret_cast<float4*>(&pb[t_u[u] * 4096 + ci * 64 + 4 * i]) =
+                        make_float4(acc[u][ja * 4 + 0][r], acc[u][ja * 4 + 1][r], acc[u][ja * 4 + 2][r], acc[u][ja * 4 + 3][r]);
+                }
+        }
+    }
+}
+
 // out[y*y_stride + tap_off[NT*z + t] + ci*s_ci + co*s_co] = sum_blk part[(z,y)][blk][t][ci][co];
 // db[64*y + co] = sum_blk db_part[(0,y)][blk][co]
 struct WgradOut {
@@ -1032,6 +1215,12 @@ extern "C" size_t cmvae_conv_wgrad_workspace_bytes(int rows_total) {
     return align_up((size_t)nblk * 4 * 4096 * sizeof(float)) + align_up((size_t)nblk * 64 * sizeof(float));
 }
 
+// CMVAE_WGRAD_STREAM=0 keeps every launch on the LDS-staged kernel (A/B measurements)
+static bool wgrad_stream_enabled() {
+    static const bool on = [] { const char* e = getenv("CMVAE_WGRAD_STREAM"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // ny 64-column blocks of G (dW advances by y_stride per block) x the taps of g, in as few launches as possible
 static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale, const float* a_shift,
                         const float* G, int g_pitch, int g_col, const int64_t* tap_off_host, int64_t s_ci,
@@ -1055,6 +1244,11 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
         float* dbp = (db && t0 == 0) ? db_part : nullptr;
         const dim3 grid(nblk, ny, nz);
         const bool pm = g.pm_nimg > 0;
+        const int npix = g.Hg * g.Wg, nimg = g.rows_total / npix;
+        if (wgrad_stream_enabled() && g.rows_total % npix == 0 && nimg % 16 == 0) {
+            if (a_scale) hipLaunchKernelGGL(conv_wgrad_stream_kernel<true>, grid, dim3(256), 0, st, g, t0, nt, nimg, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp);
+            else hipLaunchKernelGGL(conv_wgrad_stream_kernel<false>, grid, dim3(256), 0, st, g, t0, nt, nimg, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp);
+        } else {
 #define CMVAE_WGRAD(NT, HAS_T, PM) \
         hipLaunchKernelGGL((conv_wgrad_kernel<NT, HAS_T, PM>), grid, dim3(256), 0, st, g, t0, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp)
 #define CMVAE_WGRAD_NT(NT)                                                     \
@@ -1068,6 +1262,7 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
         }
 #undef CMVAE_WGRAD_NT
 #undef CMVAE_WGRAD
+        }
         if (int e = check_launch("conv_wgrad_kernel")) return e;
         for (int t = 0; t < nt * nz; ++t) o.tap_off[t] = tap_off_host[t0 + t];
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nt * 64 + 1, ny, nz), dim3(1024), 0, st, part, nblk, nt, o, dW,

@@ -10,10 +10,12 @@ ten semi-supervised EM iterations of three launches each) that occupies a fracti
   * so every stream replays its call from a captured graph (host cost of a replay: ~15 us): the chains overlap and
     the host keeps up.
 The calls do not depend on each other; results come back in submission order.  Inputs are copied into per-stream
-static buffers, outputs are cloned out of them, the reparametrisation noise is drawn inside the graph from the
-default generator's graph-safe Philox state (one fixed-size draw per replay, in submission order): the same
-distribution as the eager loop's `randn`, not the same realisation — `use_graphs=False` (or `--eval-streams 1`)
-keeps the eager draws; on the streams alone that gives 4700 episodes/s, with the graphs 5200-5700 (one box, B = 4).
+static buffers, outputs are cloned out of them.  The reparametrisation noise is NOT drawn inside the graphs: every
+graph of a generator shares one device-side Philox offset, which the replays of different streams would overwrite
+under each other.  Each call's noise is drawn eagerly, on the host thread in submission order, into the slot's
+static buffer (the same generator calls as the sequential loop, so the same realisation and bit-identical labels)
+and handed to `prediction(..., eps=)`.  On the streams alone: 4700 episodes/s, with the graphs 5200-5700 (one box,
+B = 4).
 """
 import torch
 
@@ -41,17 +43,20 @@ class PredictionPipeline:
         self.i = 0
         self.out = []
 
+    def _eps_shape(self, X_tr, X_te):
+        m = self.model
+        return (X_tr.shape[0], X_tr.shape[1] + X_te.shape[1], m.train_mc_sample_size, m.latent_size)
+
     def _capture(self, slot, key, X_tr, y_tr, X_te):
         """Static input buffers + one captured `prediction` call on the slot's stream (called on that stream)."""
         sx_tr, sy_tr, sx_te = X_tr.clone(), y_tr.clone(), X_te.clone()
-        rng = torch.cuda.get_rng_state(self.device)      # warm-up and capture must not consume the noise stream
+        seps = torch.zeros(self._eps_shape(X_tr, X_te), device=self.device, dtype=torch.float32)
         for _ in range(2):                               # lazy initialisations happen outside the capture
-            self.model.prediction(sx_tr, sy_tr, sx_te)
+            self.model.prediction(sx_tr, sy_tr, sx_te, eps=seps)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=slot.stream):
-            y = self.model.prediction(sx_tr, sy_tr, sx_te)
-        torch.cuda.set_rng_state(rng, self.device)
-        slot.graphs[key] = (graph, sx_tr, sy_tr, sx_te, y)
+            y = self.model.prediction(sx_tr, sy_tr, sx_te, eps=seps)
+        slot.graphs[key] = (graph, sx_tr, sy_tr, sx_te, seps, y)
         return slot.graphs[key]
 
     def submit(self, X_tr, y_tr, X_te):
@@ -68,7 +73,8 @@ class PredictionPipeline:
             if self.use_graphs:
                 key = (tuple(X_tr.shape), tuple(y_tr.shape), tuple(X_te.shape), X_tr.dtype)
                 entry = slot.graphs.get(key) or self._capture(slot, key, X_tr, y_tr, X_te)
-                graph, sx_tr, sy_tr, sx_te, y_static = entry
+                graph, sx_tr, sy_tr, sx_te, seps, y_static = entry
+                torch.randn(seps.shape, out=seps)        # the eager loop's draw, in submission order
                 sx_tr.copy_(X_tr, non_blocking=True)
                 sy_tr.copy_(y_tr, non_blocking=True)
                 sx_te.copy_(X_te, non_blocking=True)

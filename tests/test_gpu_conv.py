@@ -19,7 +19,7 @@ def from_nhwc(m, n, H, W):
     return m.view(n, H, W, -1).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize('n,H,W', [(3, 7, 7), (5, 14, 14), (2, 4, 4), (130, 2, 2)])
+@pytest.mark.parametrize('n,H,W', [(3, 7, 7), (5, 14, 14), (2, 4, 4), (130, 2, 2), (16, 7, 7), (48, 5, 3), (160, 2, 2)])
 def test_conv3x3_fwd_dgrad_wgrad(device, n, H, W):
     from cmvae_amd import conv
     g = torch.Generator().manual_seed(n)
@@ -54,7 +54,11 @@ def test_conv3x3_fwd_dgrad_wgrad(device, n, H, W):
 
 @pytest.mark.parametrize('n,Hi,k,pm', [(6, 2, 4, False), (5, 4, 3, False), (3, 7, 4, False), (70, 7, 4, False),
                                           (6, 2, 4, True), (5, 4, 3, True), (70, 7, 4, True), (256, 7, 4, True),
-                                          (300, 4, 3, True), (641, 2, 4, True), (200, 7, 4, True)])
+                                          (300, 4, 3, True), (641, 2, 4, True), (200, 7, 4, True),
+                                          # image counts that are multiples of 16: the streaming weight-gradient kernel
+                                          # (1, 2 and 4 taps per phase; fewer chunks than streams; either row order)
+                                          (16, 2, 4, False), (32, 4, 3, False), (48, 7, 4, False), (304, 4, 3, True),
+                                          (1024, 7, 4, True), (2000, 2, 4, True)])
 def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
     """Transposed conv over relu(bn(x)) folded into the operand load; dgrad; wgrad.  pm: pixel-major row order
     (rows enumerate (y, x, image); tiles that sit at one grid position skip the taps outside the image) — image
@@ -120,7 +124,7 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
 
 
 @pytest.mark.parametrize('rows,K,N,act', [(300, 128, 256, 2), (1000, 256, 256, 1), (77, 256, 128, 0),
-                                          (513, 64, 2048, 0)])
+                                          (513, 64, 2048, 0), (1008, 192, 128, 1), (4800, 256, 64, 0), (16, 64, 64, 0)])
 def test_linear_fwd_dgrad_wgrad(device, rows, K, N, act):
     from cmvae_amd import conv
     g = torch.Generator().manual_seed(rows)

@@ -51,7 +51,8 @@ def _check_step(model, oracle, out_o, ex_o, out_g, ex_g):
     for i, n in enumerate(('rec_loss', 'kl_loss', 'h_augment'), start=1):
         _scalar_close(n, out_g[i], out_o[i])
     # bare h: the oracle's own `trace - 64` cancels at ulp(64) = 7.6e-6
-    assert abs(float(out_g[4]) - float(out_o[4])) <= RTOL * abs(float(out_o[4])) + 64 * 6e-8 * 8
+    hg, ho = float(out_g[4].detach()), float(out_o[4].detach())
+    assert abs(hg - ho) <= RTOL * abs(ho) + 64 * 6e-8 * 8
     e = rel_err(out_g[0], out_o[0])
     print('  reconstruction rel %.2e' % e)
     assert e < RTOL

@@ -84,7 +84,8 @@ def _check_forward(model, oracle, out_o, ex_o, out_g, ex_g):
         a, b = float(out_g[i]), float(out_o[i])
         assert abs(a - b) <= RTOL * abs(b) + 1e-7, '%s: gpu %r oracle %r' % (n, a, b)
     # bare h suffers the oracle's own `trace - 64` cancellation: compare at the fp32-ulp(64) floor
-    assert abs(float(out_g[4]) - float(out_o[4])) <= RTOL * abs(float(out_o[4])) + 64 * 6e-8 * 8
+    hg, ho = float(out_g[4].detach()), float(out_o[4].detach())
+    assert abs(hg - ho) <= RTOL * abs(ho) + 64 * 6e-8 * 8
     assert rel_err(out_g[0], out_o[0]) < RTOL                               # reconstructions
     for key in ('q_z_mean', 'q_z_logvar', 'mu_k', 'pi_k', 'log_p_z', 'log_q_z', 'log_p_eps'):
         assert rel_err(ex_g[key].reshape(-1), ex_o[key].reshape(-1)) < RTOL, key

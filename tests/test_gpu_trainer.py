@@ -87,11 +87,9 @@ def test_cli_entry_point_in_a_fresh_process(tmp_path):
 
 
 def test_prediction_pipeline_equals_sequential_calls(device):
-    """Independent few-shot calls dealt to several HIP streams (cmvae_amd/pipeline.py, what Trainer.eval does).
-    Launched eagerly on the streams they return the labels of the sequential loop bit for bit, in submission order
-    (the noise is drawn on the host thread in call order).  Replayed from HIP graphs the noise comes from the
-    generator's graph-safe Philox state — the same distribution, another realisation than the eager loop's — so the
-    replayed runs are compared with each other: any number of streams gives the single-stream replay's labels."""
+    """Independent few-shot calls dealt to several HIP streams (cmvae_amd/pipeline.py, what Trainer.eval does), launched
+    eagerly or replayed from HIP graphs: the labels of the sequential loop bit for bit, in submission order, for any
+    number of streams (the noise of every call is drawn on the host thread in call order, outside the graphs)."""
     import torch
     from cmvae_amd.pipeline import PredictionPipeline
     from tests.helpers import build_pair, omniglot_batch
@@ -113,16 +111,9 @@ def test_prediction_pipeline_equals_sequential_calls(device):
 
     torch.manual_seed(3)
     ref = [model.prediction(X[:, :tr].contiguous(), y_tr, X[:, tr:].contiguous()) for X in episodes]
-    for n_streams in (1, 3):
-        for a, b in zip(run(n_streams, False), ref):
-            assert torch.equal(a, b), n_streams
-    ref_g = run(1, True)
-    for n_streams, graphs in ((3, True), (4, None)):
-        for a, b in zip(run(n_streams, graphs), ref_g):
-            assert torch.equal(a, b), n_streams
-    # replayed and eager calls see the same inputs and weights: with the noise switched off (M large enough that the
-    # MC average decides) they need not agree label for label, but both must be valid labellings
-    assert all(int(y.min()) >= 0 and int(y.max()) < K for y in ref_g)
+    for n_streams, graphs in ((1, False), (3, False), (1, True), (3, True), (4, None)):
+        for a, b in zip(run(n_streams, graphs), ref):
+            assert torch.equal(a, b), (n_streams, graphs)
     # a second shape on the same pipeline captures a second graph
     pipe = PredictionPipeline(model, 2)
     X5 = omniglot_batch(B, 2 * K + K * query, seed=77).to(device)
