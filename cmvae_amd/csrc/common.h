@@ -39,6 +39,22 @@ inline int resident_blocks(const void* kernel, int block_threads, int fallback) 
     return cus * occ;
 }
 
+// Compute units of the current device (256 on MI355X, also the answer when no device is present: the workspace-size
+// queries are pure host functions).  Grids of persistent kernels whose occupancy is fixed by their launch bounds are
+// `compute_units() * workgroups per CU`.
+inline int compute_units() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        return n;
+    }();
+    return cus;
+}
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // expm1 accurate to ~2e-7 relative without the cost of ocml's expm1f.

@@ -701,8 +701,9 @@ static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, cons
     const int ntiles = (g.rows_total + 32 * NW - 1) / (32 * NW);
     // resident workgroups: two (NW = 4) or one (NW = 8) per CU
     static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM>, 64 * NW,
-                                           NW == 4 ? 512 : 256);
-    const int cap_use = cap < (NW == 4 ? 512 : 256) ? cap : (NW == 4 ? 512 : 256);
+                                           (NW == 4 ? 2 : 1) * compute_units());
+    const int most = (NW == 4 ? 2 : 1) * compute_units();
+    const int cap_use = cap < most ? cap : most;
     const dim3 grid(ntiles < cap_use ? ntiles : cap_use, n_col_blocks);
     hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
                        a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps);
@@ -1141,7 +1142,7 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
 
 static int gemm_grid(int rows_total, int nblk_cols) {
     const int ntiles = (rows_total + BM - 1) / BM;
-    int gx = 768 / (nblk_cols > 0 ? nblk_cols : 1);
+    int gx = 3 * compute_units() / (nblk_cols > 0 ? nblk_cols : 1);      // launch bounds: three workgroups per CU
     if (gx < 64) gx = 64;
     return ntiles < gx ? (ntiles > 0 ? ntiles : 1) : gx;
 }
@@ -1149,7 +1150,8 @@ static int gemm_grid(int rows_total, int nblk_cols) {
 // weight-gradient blocks: two per CU (64 KB of LDS each), every block leaves one partial per tap
 static int wgrad_grid(int rows_total) {
     const int ntiles = (rows_total + BM - 1) / BM;
-    return ntiles < 512 ? (ntiles > 0 ? ntiles : 1) : 512;
+    const int cap = 2 * compute_units();
+    return ntiles < cap ? (ntiles > 0 ? ntiles : 1) : cap;
 }
 
 extern "C" int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks) {

@@ -835,7 +835,7 @@ static int pick_tiles_per_block(int B, int N, int K, bool dz = false) {
     if (B < 1) B = 1;
     int tiles_ep = (N + TRP - 1) / TRP;
     if (tiles_ep < 1) tiles_ep = 1;
-    const int resident = (K <= 16 && !dz) ? 768 : 512;
+    const int resident = compute_units() * ((K <= 16 && !dz) ? 3 : 2);
     int nblk = resident / B;                             // workgroups per episode: at most one resident round
     if (nblk > tiles_ep) nblk = tiles_ep;
     if (nblk < 1) nblk = 1;
