@@ -92,3 +92,17 @@ def test_size_queries_survive_degenerate_shapes():
               lib.cmvae_conv_gemm_grid(0, 1), lib.cmvae_rowpass_grid(0), lib.cmvae_dec_out_grid(0),
               lib.cmvae_causal_lc_bwd_grid(0), lib.cmvae_center_rows_chunks(0)):
         assert q >= 0
+
+
+def test_torch_ops_namespace_lists_every_leaf_op():
+    """torch.ops.cmvae_amd.* (cmvae_amd/ops.py + registry.py) exists for every registered name without a GPU; the
+    geometry struct survives the trip through its int-list form."""
+    import torch
+    import cmvae_amd.registry as reg
+    from cmvae_amd import conv
+    for name in reg.REGISTERED:
+        assert hasattr(torch.ops.cmvae_amd, name), name
+    for g in (conv.geom_conv3x3(3, 7, 7), conv.geom_convT_phase(64, 7, 7, 4, 1, 0, pixel_major=True)[0],
+              conv.geom_linear(10, 128, 256)):
+        lst = reg.geom_to_list(g)
+        assert reg.geom_to_list(reg.geom_from_list(lst)) == lst
