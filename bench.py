@@ -121,7 +121,15 @@ def roofline_em_pass(device, shapes):
         alg_bytes = B * (N * 64 * 4 + K * (2 * 64 + 2) * 4)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         name = 'em_pass_kernel<%d, false, false>' % ((K + 1) // 2)     # the instantiation this shape launches
-        traffic, src = pmc_traffic(lambda k: k == name)
+        # shapes that share an instantiation share its PMC record: the largest takes the record's largest launch, the
+        # others report no traffic (the launch-weighted mean would mix the shapes)
+        same = [b * (n * 64 * 4 + k * 130 * 4) for _, (b, n, k) in shapes if (k + 1) // 2 == (K + 1) // 2]
+        if len(same) == 1:
+            traffic, src = pmc_traffic(lambda k: k == name)
+        elif alg_bytes == max(same):
+            traffic, src = pmc_traffic(lambda k: k == name, largest=True)
+        else:
+            traffic, src = None, None
         out.append({'kernel': 'em_pass_kernel', 'shape': tag, 'bound': 'hbm', 'achieved': round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                     'traffic_source': src,
@@ -143,7 +151,7 @@ def useful_flops(g, ncb):
     return 2.0 * 64 * 64 * taps * n_img * ncb
 
 
-def pmc_traffic(select):
+def pmc_traffic(select, largest=False):
     """HBM bytes per launch, launch-weighted over the kernels whose rocprof name satisfies `select`, from the newest
     committed rocprofv3 PMC summary (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes over this same
     workload, gfx950 correction applied).  PMC counters cannot be read from inside this process."""
@@ -157,6 +165,8 @@ def pmc_traffic(select):
     n = sum(v['launches'] for v in sel)
     if not n:
         return None, None
+    if largest:
+        return max(v['max_launch_read_bytes'] + v['max_launch_write_bytes'] for v in sel), os.path.basename(files[-1])
     return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / n, os.path.basename(files[-1])
 
 
