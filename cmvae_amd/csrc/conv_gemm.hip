@@ -15,6 +15,9 @@
 #ifndef CMVAE_ABLATE
 #define CMVAE_ABLATE 0
 #endif
+#ifndef CMVAE_STAGGER
+#define CMVAE_STAGGER 0
+#endif
 
 namespace cmvae {
 
@@ -915,7 +918,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
     const int nchunks = (nimg / 16) * npix;
     const int nstreams = (int)gridDim.x * P, sid = (int)blockIdx.x * P + p;
     const int c_begin = (int)((long)nchunks * sid / nstreams), c_end = (int)((long)nchunks * (sid + 1) / nstreams);
-    const int t_u[2] = {2 * tp, 2 * tp + 1};                     // the wave's taps within the launch group
+    // the wave's taps within the launch group.  Four taps are a product set {a,b} x {c,d} of row and column offsets:
+    // pairing (a,c) with (b,d) and (a,d) with (b,c) gives both pairs the same number of in-image positions (85 / 84 of
+    // a 7x7 grid; consecutive pairs would be 91 / 78 and the kernel would run at the pace of the heavier pair)
+    const int t_u[2] = {split ? tp : 0, split ? 3 - tp : 1};
     const int img_a = g.Hi * g.Wi * g.a_pitch, img_g = g.Ho * g.Wo * g_pitch;
 
     float4 sc[2], sh[2];
@@ -949,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
         const int op = (img * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
         d.go = (live ? op * g_pitch + g_col : 0) + 4 * i;
         d.sg = live ? 4 * img_g : 0;
-#if CMVAE_ABLATE == 7      // every operand load hits the same 256 bytes: the MFMA-side ceiling of this loop
+#if CMVAE_ABLATE == 7 || CMVAE_ABLATE == 8      // (8: and no tap is skipped) every operand load hits the same 256 bytes: the MFMA-side ceiling of this loop
         d.a[0] = d.a[1] = d.go = 4 * i; d.sa[0] = d.sa[1] = d.sg = 0;
 #endif
         return d;
@@ -975,7 +981,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
         const float gb[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+#if CMVAE_ABLATE != 8
             if (!((valid >> u) & 1u)) continue;                  // uniform
+#endif
             const float4 a = transform_a<HAS_T>(ra[slot][u], true, sc[u], sh[u]);
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -990,6 +998,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
     int ib = c / npix;
     int y, x;
     { const int pix = c - ib * npix; y = pix / g.Wg; x = pix - y * g.Wg; }
+#if CMVAE_STAGGER
+    // the two workgroups of a CU start half a chunk apart, so that one's address / descriptor work falls into the
+    // other's MFMA phase instead of both alternating in lock step
+    if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(CMVAE_STAGGER);
+#endif
     ChunkDesc cur = describe(ib, y, x, c < c_end);
 #pragma unroll
     for (int s = 0; s < 4; ++s) issue(s, cur, s);

@@ -1,5 +1,6 @@
 """Layer-3 weight gradient (4 phases x 4 taps, 38400 images, BatchNorm fold): time per phase launch, in isolation.
 CMVAE_WGRAD_STREAM=0 -> the LDS-staged kernel; CMVAE_HIP_LIB=<ablation build> -> operand loads that always hit L1."""
+import os
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -11,6 +12,8 @@ x = torch.empty(n * 49, 64, device=dev).normal_(generator=g)
 gy = torch.empty(n * 196, 64, device=dev).normal_(generator=g)
 sc = torch.rand(64, device=dev) + 0.5
 sh = torch.randn(64, device=dev) * 0.3
+if os.environ.get('NO_FOLD'):
+    sc = sh = None
 dW = torch.zeros(64, 64, k, k, device=dev)
 db = torch.zeros(64, device=dev)
 for pm in (True, False):
