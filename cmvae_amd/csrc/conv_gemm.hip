@@ -1260,7 +1260,9 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
         const dim3 grid(nblk, ny, nz);
         const bool pm = g.pm_nimg > 0;
         const int npix = g.Hg * g.Wg, nimg = g.rows_total / npix;
-        if (wgrad_stream_enabled() && g.rows_total % npix == 0 && nimg % 16 == 0) {
+        // (the streaming kernel addresses the gradient with 32-bit element offsets, like the operand)
+        if (wgrad_stream_enabled() && g.rows_total % npix == 0 && nimg % 16 == 0 &&
+            (long)nimg * g.Ho * g.Wo * g_pitch < (1L << 31)) {
             if (a_scale) hipLaunchKernelGGL(conv_wgrad_stream_kernel<true>, grid, dim3(256), 0, st, g, t0, nt, nimg, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp);
             else hipLaunchKernelGGL(conv_wgrad_stream_kernel<false>, grid, dim3(256), 0, st, g, t0, nt, nimg, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp);
         } else {
