@@ -163,15 +163,25 @@ __device__ __forceinline__ float4 load_a(const ConvGeom& g, const float* __restr
     return *reinterpret_cast<const float4*>(A + off + 4 * q);
 }
 
-// previous layer's BatchNorm + ReLU folded into the operand load; padding stays exactly zero
+// previous layer's BatchNorm + ReLU folded into the operand load; padding stays exactly zero.
+// On this hardware every VALU instruction of a wave takes its 4-8 cycles out of the SIMD's MFMA time (nothing overlaps:
+// tools/mfma_power.hip, 32 VALU ops next to 32 MFMAs cost 13 %), so the fold is written for the fewest instructions:
+// v_pk_fma_f32 on channel pairs, one v_max per channel, and the zeroing of rows outside the image only on waves that
+// have such a row (`fold_a` is the version for waves whose 64 rows are all inside).
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+template <bool HAS_T>
+__device__ __forceinline__ float4 fold_a(float4 v, const float4& sc, const float4& sh) {
+    if (HAS_T) {
+        floatx2 lo = {v.x, v.y}, hi = {v.z, v.w};
+        lo = __builtin_elementwise_fma(lo, floatx2{sc.x, sc.y}, floatx2{sh.x, sh.y});
+        hi = __builtin_elementwise_fma(hi, floatx2{sc.z, sc.w}, floatx2{sh.z, sh.w});
+        v.x = fmaxf(lo.x, 0.f); v.y = fmaxf(lo.y, 0.f); v.z = fmaxf(hi.x, 0.f); v.w = fmaxf(hi.y, 0.f);
+    }
+    return v;
+}
 template <bool HAS_T>
 __device__ __forceinline__ float4 transform_a(float4 v, bool ok, const float4& sc, const float4& sh) {
-    if (HAS_T) {
-        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-        v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-        v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-    }
+    v = fold_a<HAS_T>(v, sc, sh);
     v.x = ok ? v.x : 0.f;
     v.y = ok ? v.y : 0.f;
     v.z = ok ? v.z : 0.f;
@@ -406,7 +416,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
         const int dy = g.dy[t], dx = g.dx[t];
         const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[t];
         const bool ok = ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
+#if CMVAE_ABLATE == 11 || CMVAE_ABLATE == 13     // every operand load hits the same 8 KB
+        const float* p = A + (ok ? (ri.off + delta) & 2047 : 0) + 4 * h;
+#else
         const float* p = A + (ok ? ri.off + delta : 0) + 4 * h;
+#endif
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float4 v = *reinterpret_cast<const float4*>(p + 8 * kk);
@@ -567,8 +581,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
     const int ntiles = (g.rows_total + BMT - 1) / BMT;
     const RowDecoder dec(g);
     float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
+    floatx2 sum0p = {0.f, 0.f}, sum1p = sum0p, sq0p = sum0p, sq1p = sum0p;      // fast epilogue: sums over even / odd rows
     const float b0 = bias ? bias[nb * 64 + i] : 0.f;
     const float b1 = bias ? bias[nb * 64 + 32 + i] : 0.f;
+    // uniform: every output byte offset fits 32 bits and every pixel index 24 (v_mad_u32_u24)
+    const bool out_off32 = (long)(g.rows_total / (g.Hg * g.Wg)) * g.Ho * g.Wo < (1L << 24) &&
+                           (long)(g.rows_total / (g.Hg * g.Wg)) * g.Ho * g.Wo * g.o_pitch * 4 < (1L << 32) &&
+                           (long)g.o_pitch * 4 < (1L << 24);
     __syncthreads();                                               // the only barrier before the statistics
 
     RowInfo ri;
@@ -590,7 +609,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
         const int dy = g.dy[tap0 + t], dx = g.dx[tap0 + t];
         const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[tap0 + t];
         ok_next = ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
+#if CMVAE_ABLATE == 11 || CMVAE_ABLATE == 13     // every operand load hits the same 8 KB
+        const float* p = A + (ok_next ? (ri.off + delta) & 2047 : 0) + 4 * h;
+#else
         const float* p = A + (ok_next ? ri.off + delta : 0) + 4 * h;
+#endif
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ra[kk] = *reinterpret_cast<const float4*>(p + 8 * kk);
     };
@@ -606,8 +629,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
         float4 a[8];
         {
             const bool ok = ok_next;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) {        // uniform: every row of the wave is inside the image
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<HAS_T>(ra[kk], ok, sc[HAS_T ? kk : 0], sh[HAS_T ? kk : 0]);
+                for (int kk = 0; kk < 8; ++kk) a[kk] = fold_a<HAS_T>(ra[kk], sc[HAS_T ? kk : 0], sh[HAS_T ? kk : 0]);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<HAS_T>(ra[kk], ok, sc[HAS_T ? kk : 0], sh[HAS_T ? kk : 0]);
+            }
         }
         const unsigned rest = taps_above(mask, t);
         const bool last = rest == 0;                               // uniform: the tile's last valid tap
@@ -647,7 +675,37 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
             p4 = pn; r4 = rn;
         }
-        if (last) {
+        if (last && tile * BMT + 32 * w + 31 < g.rows_total && out_off32) {
+            // every row of the wave exists and the output fits 32-bit byte offsets (the common case): no per-row
+            // predicate, packed bias / statistics arithmetic on row pairs, scalar base + one VGPR offset per store
+            const int* op_w = opix + (par * NW + w) * 32;
+            const floatx2 bb0 = {b0, b0}, bb1 = {b1, b1};
+            const unsigned col_b = (unsigned)(nb * 64 + i) * 4u, pitch_b = (unsigned)g.o_pitch * 4u;
+            const char* ob = reinterpret_cast<const char*>(out);
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int4 ops = *reinterpret_cast<const int4*>(&op_w[8 * rq + 4 * h]);
+                const int opv[4] = {ops.x, ops.y, ops.z, ops.w};
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const floatx2 v0 = floatx2{acc0[4 * rq + r], acc0[4 * rq + r + 1]} + bb0;
+                    const floatx2 v1 = floatx2{acc1[4 * rq + r], acc1[4 * rq + r + 1]} + bb1;
+                    sum0p += v0; sq0p = __builtin_elementwise_fma(v0, v0, sq0p);
+                    sum1p += v1; sq1p = __builtin_elementwise_fma(v1, v1, sq1p);
+#if !(CMVAE_ABLATE == 12 || CMVAE_ABLATE == 13)
+                    float* o0 = (float*)(ob + (__umul24((unsigned)opv[r], pitch_b) + col_b));
+                    float* o1 = (float*)(ob + (__umul24((unsigned)opv[r + 1], pitch_b) + col_b));
+                    o0[0] = apply_act<ACT>(v0.x); o0[32] = apply_act<ACT>(v1.x);
+                    o1[0] = apply_act<ACT>(v0.y); o1[32] = apply_act<ACT>(v1.y);
+#endif
+                }
+            }
+            acc0 = floatx16{};
+            acc1 = floatx16{};
+            par ^= 1;
+            tile = ntile;
+            mask = nmask;
+        } else if (last) {
             const int* op_w = opix + (par * NW + w) * 32;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -657,8 +715,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
                     const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
                     ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
                     ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
+#if CMVAE_ABLATE == 12 || CMVAE_ABLATE == 13     // no output stores (the statistics keep the accumulators alive)
+                    if (v0 == 1.2345e33f) o[i] = v1;
+#else
                     o[i] = apply_act<ACT>(v0);
                     o[32 + i] = apply_act<ACT>(v1);
+#endif
                 }
             }
             acc0 = floatx16{};
@@ -670,6 +732,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
         t = tn;
     }
     if (stats_part) {
+        ssum0 += sum0p.x + sum0p.y; ssum1 += sum1p.x + sum1p.y;
+        ssq0 += sq0p.x + sq0p.y; ssq1 += sq1p.x + sq1p.y;
         ssum0 += __shfl_xor(ssum0, 32); ssum1 += __shfl_xor(ssum1, 32);
         ssq0 += __shfl_xor(ssq0, 32); ssq1 += __shfl_xor(ssq1, 32);
         if (h == 0) {
@@ -883,11 +947,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
 // into tap pairs x row streams and add their accumulators through LDS once, at the end.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-struct ChunkDesc {
-    int a[2];                 // per-lane element offsets of the two taps' operand rows (group 0)
+struct ChunkDesc {            // all uniform (SGPRs): the per-lane part of every address is a kernel-wide constant
+    int a[2];                 // element offsets of the two taps' operand rows (image 16*ib, group 0)
     int go;                   // ... of the gradient row
-    int sa[2], sg;            // uniform: offset step between 4-row groups (0 for a skipped tap / dead chunk)
-    unsigned valid;           // uniform: bit u = tap u inside the image, bit 2 = chunk inside the range
+    int sa[2], sg;            // offset step between 4-row groups (0 for a skipped tap / dead chunk)
+    unsigned valid;           // bit u = tap u inside the image, bit 2 = chunk inside the range
 };
 
 template <bool HAS_T>
@@ -933,9 +997,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
             sh[u] = *reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t_u[u]] + 4 * i);
         }
     }
+    // lane (i, kq): channels 4i .. 4i+3 of image kq of a 4-row group; everything else of an address is uniform, so the
+    // loads take a scalar base and this one VGPR offset (no per-load vector address arithmetic)
+    const int lane_a = kq * img_a + 4 * i, lane_g = kq * img_g + 4 * i;
     auto describe = [&](int ib, int y, int x, bool live) {
         ChunkDesc d;
-        const int img = ib * 16 + kq;
+        const int img = ib * 16;
         const int ys = y * g.sy, xs = x * g.sx;
         d.valid = live ? 4u : 0u;
 #pragma unroll
@@ -948,15 +1015,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
                 in = live & ((unsigned)(ys + dy) < (unsigned)g.Hi) & ((unsigned)(xs + dx) < (unsigned)g.Wi);
                 off = ((img * g.Hi + ys + dy) * g.Wi + xs + dx) * g.a_pitch + g.a_col[t];
             }
-            d.a[u] = (in ? off : 0) + 4 * i;
+            d.a[u] = in ? off : 0;
             d.sa[u] = in ? 4 * img_a : 0;
             d.valid |= in ? (1u << u) : 0u;
         }
         const int op = (img * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
-        d.go = (live ? op * g_pitch + g_col : 0) + 4 * i;
+        d.go = live ? op * g_pitch + g_col : 0;
         d.sg = live ? 4 * img_g : 0;
-#if CMVAE_ABLATE == 7 || CMVAE_ABLATE == 8      // (8: and no tap is skipped) every operand load hits the same 256 bytes: the MFMA-side ceiling of this loop
-        d.a[0] = d.a[1] = d.go = 4 * i; d.sa[0] = d.sa[1] = d.sg = 0;
+#if CMVAE_ABLATE == 7 || CMVAE_ABLATE == 8 || CMVAE_ABLATE == 9      // (8: and no tap is skipped) every operand load hits the same few rows: the MFMA-side ceiling of this loop
+        d.a[0] = d.a[1] = d.go = 0; d.sa[0] = d.sa[1] = d.sg = 0;
 #endif
         return d;
     };
@@ -967,17 +1034,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[u][k] = floatx4{0.f, 0.f, 0.f, 0.f};
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool want_db = db_part != nullptr && tp == 0;
+    const float db_on = (db_part != nullptr && tp == 0) ? 1.f : 0.f;
 
     float4 ra[4][2], rg[4];
     auto issue = [&](int slot, const ChunkDesc& d, int s) {
-        ra[slot][0] = *reinterpret_cast<const float4*>(A + d.a[0] + s * d.sa[0]);
-        ra[slot][1] = *reinterpret_cast<const float4*>(A + d.a[1] + s * d.sa[1]);
-        rg[slot] = *reinterpret_cast<const float4*>(G + d.go + s * d.sg);
+        const float* a0 = A + (d.a[0] + s * d.sa[0]);            // uniform pointers
+        const float* a1 = A + (d.a[1] + s * d.sa[1]);
+        const float* gp = G + (d.go + s * d.sg);
+        ra[slot][0] = *reinterpret_cast<const float4*>(a0 + lane_a);
+        ra[slot][1] = *reinterpret_cast<const float4*>(a1 + lane_a);
+        rg[slot] = *reinterpret_cast<const float4*>(gp + lane_g);
     };
     auto consume = [&](int slot, unsigned valid) {
         const float4 gv = rg[slot];
-        if (want_db && (valid & 4u)) { dbs.x += gv.x; dbs.y += gv.y; dbs.z += gv.z; dbs.w += gv.w; }
+        // every consumed chunk is inside the range (only the prefetch past the end is not); the bias-gradient sum is
+        // two packed FMAs with a 0/1 factor instead of a branch or selects
+        {
+            floatx2 lo = {dbs.x, dbs.y}, hi = {dbs.z, dbs.w};
+            lo = __builtin_elementwise_fma(floatx2{gv.x, gv.y}, floatx2{db_on, db_on}, lo);
+            hi = __builtin_elementwise_fma(floatx2{gv.z, gv.w}, floatx2{db_on, db_on}, hi);
+            dbs = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
         const float gb[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1012,7 +1089,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             consume(s, cur.valid);
+#if CMVAE_ABLATE != 9          // 9: no loads in the main loop at all (operands stay what the prologue fetched)
             issue(s, nxt, s);
+#endif
         }
         cur = nxt;
     }
