@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 
     RowInfo ri;
     float4 ra[8], rw0, rw1, rw2, rw3;
+    bool ok_next = false;
     int par = 0;
     auto rows_of_tile = [&](int tile, const TileInfo& ti, int* op) {
         const int r = tile * BM + 32 * w + i;          // this lane's row
@@ -421,12 +422,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 #else
         const float* p = A + (ok ? ri.off + delta : 0) + 4 * h;
 #endif
+        ok_next = ok;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            float4 v = *reinterpret_cast<const float4*>(p + 8 * kk);
-            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-            ra[kk] = v;
-        }
+        for (int kk = 0; kk < 8; ++kk) ra[kk] = *reinterpret_cast<const float4*>(p + 8 * kk);   // zeroed when consumed
     };
     auto load_w = [&](int t) {
         const float* Wn1 = Wn + g.w_off[t];
@@ -451,8 +449,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
         *reinterpret_cast<float4*>(&Ws[(rb + 32) * LDA + 4 * q]) = rw2;
         *reinterpret_cast<float4*>(&Ws[(rb + 48) * LDA + 4 * q]) = rw3;
         float4 a[8];
+        if (__builtin_amdgcn_ballot_w64(ok_next) == ~0ull) {   // uniform: every row of the wave is inside the image
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) a[kk] = ra[kk];
+            for (int kk = 0; kk < 8; ++kk) a[kk] = ra[kk];
+        } else {
+            const bool ok = ok_next;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<false>(ra[kk], ok, ra[kk], ra[kk]);
+        }
         __syncthreads();
         const unsigned rest = taps_above(mask, t);
         const bool last = rest == 0;                   // uniform: the tile's last valid tap

@@ -217,10 +217,12 @@ __global__ __launch_bounds__(256) void dec_out_fwd_kernel(const float* __restric
         for (int k = 0; k < NLD; ++k) {
             const int e = tid + 256 * k;
             float4 v = pre[k];
-            v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-            v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-            v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-            v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+            {
+                typedef float floatx2 __attribute__((ext_vector_type(2)));
+                const floatx2 lo = __builtin_elementwise_fma(floatx2{v.x, v.y}, floatx2{sc.x, sc.y}, floatx2{sh.x, sh.y});
+                const floatx2 hi = __builtin_elementwise_fma(floatx2{v.z, v.w}, floatx2{sc.z, sc.w}, floatx2{sh.z, sh.w});
+                v.x = fmaxf(lo.x, 0.f); v.y = fmaxf(lo.y, 0.f); v.z = fmaxf(hi.x, 0.f); v.w = fmaxf(hi.y, 0.f);
+            }
             if (e < NPIX_I * 16) *reinterpret_cast<float4*>(&as[(e >> 4) * AL + 4 * q]) = v;
         }
         __syncthreads();
@@ -320,7 +322,7 @@ constexpr int SP = 80;                 // a3 staging pitch: A-fragment (pixel-ma
 // MODE 1: the apply pass -- recomputes dybn3 and writes dy3 = scale*(dybn3 - c1 - xhat*c2) straight away, so the
 //         masked gradient never makes a round trip through HBM (saves a 1.9 GB write and a 3.9 GB re-read).
 template <int MODE>
-__global__ __launch_bounds__(256, 3) void dec_out_bwd_kernel(const float* __restrict__ y3,
+__global__ __launch_bounds__(256, MODE == 0 ? 2 : 3) void dec_out_bwd_kernel(const float* __restrict__ y3,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ mean,
@@ -353,10 +355,15 @@ __global__ __launch_bounds__(256, 3) void dec_out_bwd_kernel(const float* __rest
         k1 = reinterpret_cast<const float4*>(c1)[i];
         k2 = reinterpret_cast<const float4*>(c2)[i];
     }
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    const floatx2 scl = {sc.x, sc.y}, sch = {sc.z, sc.w}, shl = {sh.x, sh.y}, shh = {sh.z, sh.w};
+    const floatx2 isl = {is.x, is.y}, ish = {is.z, is.w};
+    const floatx2 nml = {-mu.x * is.x, -mu.y * is.y}, nmh = {-mu.z * is.z, -mu.w * is.w};
+    const floatx2 k1l = {k1.x, k1.y}, k1h = {k1.z, k1.w}, nk2l = {-k2.x, -k2.y}, nk2h = {-k2.z, -k2.w};
     floatx4 dw[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) dw[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    floatx2 s1l = {0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l;
     float dbs = 0.f;
     for (int e = tid; e < 2 * PL * PL; e += 256) (&dl[0][0])[e] = 0.f;
     __syncthreads();
@@ -444,25 +451,26 @@ __global__ __launch_bounds__(256, 3) void dec_out_bwd_kernel(const float* __rest
                 const bool ok = px < NPIX_I;
                 const float4 gv = *reinterpret_cast<const float4*>(&gw[rr * GP + 4 * i]);
                 const float4 v = vr[j];
+                // channel pairs on v_pk_fma_f32 / v_pk_add_f32 (VALU instructions take their cycles out of the SIMD's
+                // MFMA time); xhat = v*invstd - mean*invstd in one fma
+                const floatx2 vl = {v.x, v.y}, vh = {v.z, v.w};
+                const floatx2 al = __builtin_elementwise_fma(vl, scl, shl), ah = __builtin_elementwise_fma(vh, sch, shh);
                 float4 a, o;
-                a.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                a.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+                a.x = fmaxf(al.x, 0.f); a.y = fmaxf(al.y, 0.f); a.z = fmaxf(ah.x, 0.f); a.w = fmaxf(ah.y, 0.f);
                 if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
                 o.x = a.x > 0.f ? gv.x : 0.f; o.y = a.y > 0.f ? gv.y : 0.f;
                 o.z = a.z > 0.f ? gv.z : 0.f; o.w = a.w > 0.f ? gv.w : 0.f;
+                const floatx2 xl = __builtin_elementwise_fma(vl, isl, nml), xh = __builtin_elementwise_fma(vh, ish, nmh);
+                const floatx2 ol = {o.x, o.y}, oh = {o.z, o.w};
                 if (MODE == 1) {
-                    float4 r;
-                    r.x = sc.x * (o.x - k1.x - (v.x - mu.x) * is.x * k2.x);
-                    r.y = sc.y * (o.y - k1.y - (v.y - mu.y) * is.y * k2.y);
-                    r.z = sc.z * (o.z - k1.z - (v.z - mu.z) * is.z * k2.z);
-                    r.w = sc.w * (o.w - k1.w - (v.w - mu.w) * is.w * k2.w);
-                    if (ok) *reinterpret_cast<float4*>(di + px * C + 4 * i) = r;
+                    const floatx2 rl = (__builtin_elementwise_fma(xl, nk2l, ol) - k1l) * scl;
+                    const floatx2 rh = (__builtin_elementwise_fma(xh, nk2h, oh) - k1h) * sch;
+                    if (ok) *reinterpret_cast<float4*>(di + px * C + 4 * i) = make_float4(rl.x, rl.y, rh.x, rh.y);
                     continue;
                 }
                 if (ok && dybn) *reinterpret_cast<float4*>(di + px * C + 4 * i) = o;
-                s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
-                s2.x = fmaf(o.x, (v.x - mu.x) * is.x, s2.x); s2.y = fmaf(o.y, (v.y - mu.y) * is.y, s2.y);
-                s2.z = fmaf(o.z, (v.z - mu.z) * is.z, s2.z); s2.w = fmaf(o.w, (v.w - mu.w) * is.w, s2.w);
+                s1l += ol; s1h += oh;
+                s2l = __builtin_elementwise_fma(ol, xl, s2l); s2h = __builtin_elementwise_fma(oh, xh, s2h);
                 *reinterpret_cast<float4*>(&aw[rr * SP + 4 * i]) = a;
             }
             if (MODE == 0) {      // sums pass: requested after the rows are consumed, hidden behind the dW4 MFMAs and
@@ -493,8 +501,8 @@ __global__ __launch_bounds__(256, 3) void dec_out_bwd_kernel(const float* __rest
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) red[w * 1024 + (16 * cb + 4 * g + reg) * 16 + i] = dw[cb][reg];
     float* red2 = &ast[0][0];                      // [2][4 waves][4 row groups][64]
-    *reinterpret_cast<float4*>(&red2[((0 * 4 + w) * 4 + g) * 64 + 4 * i]) = s1;
-    *reinterpret_cast<float4*>(&red2[((1 * 4 + w) * 4 + g) * 64 + 4 * i]) = s2;
+    *reinterpret_cast<float4*>(&red2[((0 * 4 + w) * 4 + g) * 64 + 4 * i]) = make_float4(s1l.x, s1l.y, s1h.x, s1h.y);
+    *reinterpret_cast<float4*>(&red2[((1 * 4 + w) * 4 + g) * 64 + 4 * i]) = make_float4(s2l.x, s2l.y, s2h.x, s2h.y);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dbs += __shfl_xor(dbs, o);
     if (lane == 0) dbred[w] = dbs;
