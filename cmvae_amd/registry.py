@@ -222,3 +222,53 @@ REGISTERED = ('mixture_loglik_fwd', 'mixture_loglik_bwd', 'reparam_logq_fwd', 'r
               'unsup_prior', 'semi_prior', 'posterior_argmax', 'causal_rows', 'gram_inverse', 'center_rows',
               'linear_fwd', 'linear_bwd', 'linear_mse_fwd', 'mse_act_bwd', 'act_bwd', 'attention_fwd', 'attention_bwd',
               'adam_step', 'conv_gemm', 'conv_wgrad')
+
+
+# ----------------------------------------------------------------------------- whole encoder / decoder
+# `encode_images` and `decoder_bce` are compositions of the leaf kernels with hand-written backward passes
+# (encoder.py / decoder.py); registered as composite ops, autograd flows through their autograd.Functions.
+# BatchNorm state travels as tensors: params = [conv.weight, conv.bias, bn.weight, bn.bias] per layer (the decoder's
+# last layer has no BatchNorm: [weight, bias]); running = [running_mean, running_var, num_batches_tracked] per BatchNorm.
+class _BNState:
+    """The attributes of nn.BatchNorm2d the HIP path reads, over tensors handed in through the dispatcher."""
+    track_running_stats = True
+
+    def __init__(self, weight, bias, running_mean, running_var, num_batches_tracked, eps, momentum):
+        self.weight, self.bias = weight, bias
+        self.running_mean, self.running_var, self.num_batches_tracked = running_mean, running_var, num_batches_tracked
+        self.eps, self.momentum = eps, (None if momentum < 0 else momentum)
+
+
+_d.define('encode_images(Tensor x, bool training, Tensor[] params, Tensor(a!)[] running, float eps, float momentum)'
+          ' -> Tensor')
+_d.define('decoder_bce(Tensor h_rec, Tensor target, int M, bool training, Tensor[] params, Tensor(a!)[] running, '
+          'float eps, float momentum) -> (Tensor, Tensor)')
+
+
+def _bn_states(params, running, n_bn, eps, momentum):
+    if len(params) < 4 * n_bn or len(running) != 3 * n_bn:
+        raise RuntimeError('cmvae_amd: %d BatchNorm layers take 4 parameter tensors and 3 running tensors each' % n_bn)
+    return tuple(_BNState(params[4 * l + 2], params[4 * l + 3], running[3 * l], running[3 * l + 1], running[3 * l + 2],
+                          eps, momentum) for l in range(n_bn))
+
+
+def _encode_images(x, training, params, running, eps, momentum):
+    from .encoder import _Encoder
+    if len(params) != 16:
+        raise RuntimeError('cmvae_amd: encode_images takes 16 parameter tensors (4 layers x conv.weight, conv.bias, '
+                           'bn.weight, bn.bias)')
+    return _Encoder.apply(x, training, _bn_states(params, running, 4, eps, momentum), *params)
+
+
+def _decoder_bce(h_rec, target, M, training, params, running, eps, momentum):
+    from .decoder import _DecoderBCE
+    if len(params) != 14:
+        raise RuntimeError('cmvae_amd: decoder_bce takes 14 parameter tensors (3 layers x 4, then the last '
+                           "layer's weight and bias)")
+    return _DecoderBCE.apply(h_rec.contiguous(), target, M, training, _bn_states(params, running, 3, eps, momentum),
+                             *params)
+
+
+_d.impl('encode_images', _encode_images, 'CompositeImplicitAutograd')
+_d.impl('decoder_bce', _decoder_bce, 'CompositeImplicitAutograd')
+REGISTERED = REGISTERED + ('encode_images', 'decoder_bce')

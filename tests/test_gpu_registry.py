@@ -115,3 +115,52 @@ def test_conv_ops_take_the_geometry_as_a_list(device):
     assert torch.equal(dWw, dWg) and torch.equal(dbw, dbg)
     with pytest.raises(RuntimeError):
         O.conv_gemm(lst[:-1], x, wt, got, b, None, None, 0, 1, False)
+
+
+def test_encoder_and_decoder_ops_with_autograd(device):
+    """torch.ops.cmvae_amd.encode_images / decoder_bce: the module-based calls of the product path, value and gradients,
+    with the BatchNorm state handed over as tensors (running statistics updated in place)."""
+    import copy
+    from cmvae_amd.model import OmniglotGMVAE
+    from cmvae_amd.encoder import encode_images
+    from cmvae_amd.decoder import decoder_bce
+    O = torch.ops.cmvae_amd
+    torch.manual_seed(2)
+    m1 = OmniglotGMVAE(component_size=5, train_mc_sample_size=4, test_mc_sample_size=4).to(device).train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(12, 1, 28, 28, generator=g) < 0.2).float().to(device)
+    h1 = encode_images(m1.encoder, x)
+    seq = m2.encoder.encoder
+    params, running = [], []
+    for l in range(4):
+        cv, bn = seq[4 * l], seq[4 * l + 1]
+        params += [cv.weight, cv.bias, bn.weight, bn.bias]
+        running += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    h2 = O.encode_images(x, True, params, running, seq[1].eps, seq[1].momentum)
+    assert torch.equal(h1, h2)
+    gy = torch.randn(h1.shape, generator=g).to(device)
+    h1.backward(gy); h2.backward(gy)
+    for p1, p2 in zip(m1.encoder.parameters(), m2.encoder.parameters()):
+        assert torch.equal(p1.grad, p2.grad)
+    for b1, b2 in zip(m1.encoder.buffers(), m2.encoder.buffers()):
+        assert torch.equal(b1, b2)
+    hr = torch.randn(24, 256, generator=g).to(device)
+    tgt = (torch.rand(6, 784, generator=g) < 0.2).float().to(device)
+    hr1, hr2 = hr.clone().requires_grad_(True), hr.clone().requires_grad_(True)
+    p1, l1 = decoder_bce(m1.decoder, hr1, tgt, 4)
+    seq = m2.decoder.decoder
+    convs, bns = (seq[0], seq[3], seq[6], seq[9]), (seq[1], seq[4], seq[7])
+    params, running = [], []
+    for l in range(3):
+        params += [convs[l].weight, convs[l].bias, bns[l].weight, bns[l].bias]
+        running += [bns[l].running_mean, bns[l].running_var, bns[l].num_batches_tracked]
+    params += [convs[3].weight, convs[3].bias]
+    p2, l2 = O.decoder_bce(hr2, tgt, 4, True, params, running, bns[0].eps, bns[0].momentum)
+    assert torch.equal(p1, p2) and torch.equal(l1, l2)
+    (l1 / 24).backward(); (l2 / 24).backward()
+    assert torch.equal(hr1.grad, hr2.grad)
+    for q1, q2 in zip(m1.decoder.parameters(), m2.decoder.parameters()):
+        assert torch.equal(q1.grad, q2.grad)
+    for b1, b2 in zip(m1.decoder.buffers(), m2.decoder.buffers()):
+        assert torch.equal(b1, b2)
