@@ -122,6 +122,41 @@ __device__ __forceinline__ TileInfo tile_info(const ConvGeom& g, int row0, int r
     ti.mask = __builtin_amdgcn_readfirstlane(m ? m : full);
     return ti;
 }
+// The tap tables of a launch held in registers: lane t (mod 32) of a wave keeps tap t's offsets, a wave-uniform tap
+// index fetches them with v_readlane (no scalar memory load and its lgkmcnt wait in front of every step's address
+// arithmetic), and a tile's in-image tap mask is one compare per lane and a ballot instead of a scalar loop over taps.
+struct TapTable {
+    int dy, dx, col, woff;
+    __device__ __forceinline__ TapTable(const ConvGeom& g, int lane) {
+        const int t = lane & 31;
+        dy = g.dy[t]; dx = g.dx[t]; col = g.a_col[t]; woff = g.w_off[t];
+    }
+    __device__ __forceinline__ int tdy(int t) const { return __builtin_amdgcn_readlane(dy, t); }
+    __device__ __forceinline__ int tdx(int t) const { return __builtin_amdgcn_readlane(dx, t); }
+    __device__ __forceinline__ int tcol(int t) const { return __builtin_amdgcn_readlane(col, t); }
+    __device__ __forceinline__ int twoff(int t) const { return __builtin_amdgcn_readlane(woff, t); }
+    // as tile_info<PM>() below, for taps tap0 .. tap0+ntaps-1 (called by all 64 lanes)
+    template <bool PM>
+    __device__ __forceinline__ TileInfo tile(const ConvGeom& g, int lane, int row0, int rows, int tap0, int ntaps) const {
+        const unsigned full = ntaps >= 32 ? 0xffffffffu : ((1u << ntaps) - 1u);
+        TileInfo ti{full};
+        if (!PM) return ti;
+        row0 = __builtin_amdgcn_readfirstlane(row0);
+        if (row0 >= g.rows_total) { ti.mask = 1u; return ti; }
+        int last = row0 + rows - 1;
+        if (last >= g.rows_total) last = g.rows_total - 1;
+        const int p0 = row0 / g.pm_nimg, p1 = last / g.pm_nimg;
+        if (p0 != p1) return ti;
+        const int y = p0 / g.Wg, x = p0 - y * g.Wg;
+        const int tl = lane & 31;
+        const bool in = (lane < 32) & (tl >= tap0) & (tl < tap0 + ntaps) &
+                        ((unsigned)(y * g.sy + dy) < (unsigned)g.Hi) & ((unsigned)(x * g.sx + dx) < (unsigned)g.Wi);
+        const unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(in) >> tap0;
+        ti.mask = m ? m : full;
+        return ti;
+    }
+};
+
 // lowest set bit at or above position `from` (mask has one): index; mask_above(m, t) = bits of m above t
 __device__ __forceinline__ int first_tap(unsigned m) { return __builtin_ctz(m); }
 __device__ __forceinline__ unsigned taps_above(unsigned m, int t) { return t >= 31 ? 0u : (m & ~((2u << t) - 1u)); }
@@ -388,8 +423,10 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
     const float b1 = bias ? bias[nb * 64 + 32 + i] : 0.f;
 
     RowInfo ri;
-    float4 ra[8], rw0, rw1, rw2, rw3;
-    bool ok_next = false;
+    // two operand register sets used alternately (the loop body is instantiated twice): the loads of step s+1 go
+    // into the set the MFMAs of step s do not read, so no register copy sits between them
+    float4 ra[8], rc[8], rw0, rw1, rw2, rw3;
+    bool ok_a = false, ok_b = false;
     int par = 0;
     auto rows_of_tile = [&](int tile, const TileInfo& ti, int* op) {
         const int r = tile * BM + 32 * w + i;          // this lane's row
@@ -413,21 +450,22 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
             if (tid < BM) op[tid] = out_pixel(g, tile * BM + tid);
         }
     };
-    auto load_frag = [&](int t) {
-        const int dy = g.dy[t], dx = g.dx[t];
-        const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[t];
+    const TapTable taps(g, lane);
+    auto load_frag = [&](int t, float4 (&dst)[8], bool& ok_dst) {
+        const int dy = taps.tdy(t), dx = taps.tdx(t);
+        const int delta = (dy * g.Wi + dx) * g.a_pitch + taps.tcol(t);
         const bool ok = ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
 #if CMVAE_ABLATE == 11 || CMVAE_ABLATE == 13     // every operand load hits the same 8 KB
         const float* p = A + (ok ? (ri.off + delta) & 2047 : 0) + 4 * h;
 #else
         const float* p = A + (ok ? ri.off + delta : 0) + 4 * h;
 #endif
-        ok_next = ok;
+        ok_dst = ok;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) ra[kk] = *reinterpret_cast<const float4*>(p + 8 * kk);   // zeroed when consumed
+        for (int kk = 0; kk < 8; ++kk) dst[kk] = *reinterpret_cast<const float4*>(p + 8 * kk);  // zeroed when consumed
     };
     auto load_w = [&](int t) {
-        const float* Wn1 = Wn + g.w_off[t];
+        const float* Wn1 = Wn + taps.twoff(t);
         rw0 = *reinterpret_cast<const float4*>(Wn1);
         rw1 = *reinterpret_cast<const float4*>(Wn1 + w16);
         rw2 = *reinterpret_cast<const float4*>(Wn1 + 2 * w16);
@@ -435,27 +473,23 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
     };
     // one software pipeline over the block's (tile, valid tap) steps
     int tile = blockIdx.x;
-    TileInfo ti = tile_info<PM>(g, tile * BM, BM, 0, g.ntaps);
+    TileInfo ti = taps.tile<PM>(g, lane, tile * BM, BM, 0, g.ntaps);
     unsigned mask = ti.mask;
     int t = first_tap(mask);
     rows_of_tile(tile, ti, opix[0]);
-    load_frag(t);
+    load_frag(t, ra, ok_a);
     load_w(t);
     floatx16 acc0 = {}, acc1 = {};
-    while (tile < ntiles) {
+    auto step = [&](float4 (&a)[8], bool& ok_cur, float4 (&nxt)[8], bool& ok_nxt) {
         __syncthreads();
         *reinterpret_cast<float4*>(&Ws[rb * LDA + 4 * q]) = rw0;
         *reinterpret_cast<float4*>(&Ws[(rb + 16) * LDA + 4 * q]) = rw1;
         *reinterpret_cast<float4*>(&Ws[(rb + 32) * LDA + 4 * q]) = rw2;
         *reinterpret_cast<float4*>(&Ws[(rb + 48) * LDA + 4 * q]) = rw3;
-        float4 a[8];
-        if (__builtin_amdgcn_ballot_w64(ok_next) == ~0ull) {   // uniform: every row of the wave is inside the image
+        if (__builtin_amdgcn_ballot_w64(ok_cur) != ~0ull) {    // uniform: some row of the wave is outside the image
+            const bool ok = ok_cur;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) a[kk] = ra[kk];
-        } else {
-            const bool ok = ok_next;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<false>(ra[kk], ok, ra[kk], ra[kk]);
+            for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<false>(a[kk], ok, a[kk], a[kk]);
         }
         __syncthreads();
         const unsigned rest = taps_above(mask, t);
@@ -464,14 +498,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
         unsigned nmask = mask;
         if (last) {
             ntile = tile + gridDim.x;
-            ti = tile_info<PM>(g, ntile * BM, BM, 0, g.ntaps);
+            ti = taps.tile<PM>(g, lane, ntile * BM, BM, 0, g.ntaps);
             nmask = ti.mask;
             tn = first_tap(nmask);
             rows_of_tile(ntile, ti, opix[par ^ 1]);    // past the block's last tile every row is invalid: element 0
         } else {
             tn = first_tap(rest);
         }
-        load_frag(tn);
+        load_frag(tn, nxt, ok_nxt);
         load_w(tn);
         __builtin_amdgcn_sched_barrier(0);
         const float* bp0 = &Ws[i * LDA + 4 * h];
@@ -526,6 +560,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
             mask = nmask;
         }
         t = tn;
+    };
+    while (tile < ntiles) {
+        step(ra, ok_a, rc, ok_b);
+        if (tile >= ntiles) break;
+        step(rc, ok_b, ra, ok_a);
     }
     if (stats_part) {
         ssum0 += __shfl_xor(ssum0, 32); ssum1 += __shfl_xor(ssum1, 32);
@@ -609,9 +648,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
         else dec.decode<1>(r, 0, set);
         if (h == 0) op[i] = opx;
     };
+    const TapTable taps(g, lane);
     auto load_frag = [&](int t) {                                  // raw loads: fold / zeroing applied when consumed
-        const int dy = g.dy[tap0 + t], dx = g.dx[tap0 + t];
-        const int delta = (dy * g.Wi + dx) * g.a_pitch + g.a_col[tap0 + t];
+        const int dy = taps.tdy(tap0 + t), dx = taps.tdx(tap0 + t);
+        const int delta = (dy * g.Wi + dx) * g.a_pitch + taps.tcol(tap0 + t);
         ok_next = ((unsigned)(ri.ys + dy) < (unsigned)g.Hi) & ((unsigned)(ri.xs + dx) < (unsigned)g.Wi);
 #if CMVAE_ABLATE == 11 || CMVAE_ABLATE == 13     // every operand load hits the same 8 KB
         const float* p = A + (ok_next ? (ri.off + delta) & 2047 : 0) + 4 * h;
@@ -623,7 +663,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
     };
     // one software pipeline over the workgroup's (tile, valid tap) steps; no block barrier inside
     int tile = blockIdx.x;
-    TileInfo ti = tile_info<PM>(g, tile * BMT, BMT, tap0, ntaps);
+    TileInfo ti = taps.tile<PM>(g, lane, tile * BMT, BMT, tap0, ntaps);
     unsigned mask = ti.mask;
     int t = first_tap(mask);
     rows_of_tile(tile, ti, opix + w * 32);
@@ -647,7 +687,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
         unsigned nmask = mask;
         if (last) {
             ntile = tile + gridDim.x;
-            ti = tile_info<PM>(g, ntile * BMT, BMT, tap0, ntaps);
+            ti = taps.tile<PM>(g, lane, ntile * BMT, BMT, tap0, ntaps);
             nmask = ti.mask;
             tn = first_tap(nmask);
             rows_of_tile(ntile, ti, opix + ((par ^ 1) * NW + w) * 32);
