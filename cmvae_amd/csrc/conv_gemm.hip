@@ -481,17 +481,23 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
     load_w(t);
     floatx16 acc0 = {}, acc1 = {};
     auto step = [&](float4 (&a)[8], bool& ok_cur, float4 (&nxt)[8], bool& ok_nxt) {
+#if CMVAE_ABLATE != 14 && CMVAE_ABLATE != 15     // 14: no weight staging at all (timing only); 15: staging but no barriers
         __syncthreads();
+#endif
+#if CMVAE_ABLATE != 14
         *reinterpret_cast<float4*>(&Ws[rb * LDA + 4 * q]) = rw0;
         *reinterpret_cast<float4*>(&Ws[(rb + 16) * LDA + 4 * q]) = rw1;
         *reinterpret_cast<float4*>(&Ws[(rb + 32) * LDA + 4 * q]) = rw2;
         *reinterpret_cast<float4*>(&Ws[(rb + 48) * LDA + 4 * q]) = rw3;
+#endif
         if (__builtin_amdgcn_ballot_w64(ok_cur) != ~0ull) {    // uniform: some row of the wave is outside the image
             const bool ok = ok_cur;
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<false>(a[kk], ok, a[kk], a[kk]);
         }
+#if CMVAE_ABLATE != 14 && CMVAE_ABLATE != 15
         __syncthreads();
+#endif
         const unsigned rest = taps_above(mask, t);
         const bool last = rest == 0;                   // uniform: the tile's last valid tap
         int tn, ntile = tile;
@@ -506,7 +512,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
             tn = first_tap(rest);
         }
         load_frag(tn, nxt, ok_nxt);
+#if CMVAE_ABLATE != 14
         load_w(tn);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const float* bp0 = &Ws[i * LDA + 4 * h];
         const float* bp1 = &Ws[(32 + i) * LDA + 4 * h];
@@ -515,10 +523,12 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float4 pn = p4, rn = r4;
+#if CMVAE_ABLATE != 14
             if (kk < 7) {
                 pn = *reinterpret_cast<const float4*>(bp0 + 8 * kk + 8);
                 rn = *reinterpret_cast<const float4*>(bp1 + 8 * kk + 8);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             const float4 a4 = a[kk];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, p4.x, acc0, 0, 0, 0);
