@@ -346,8 +346,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='o20')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--eval-calls', type=int, default=10)
-    ap.add_argument('--eval-streams', type=int, default=4,
+    ap.add_argument('--eval-calls', type=int, default=40)
+    ap.add_argument('--eval-streams', type=int, default=8,
                     help='HIP streams the independent prediction calls are dealt to, as Trainer.eval does (1 = sequential)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]

@@ -29,7 +29,7 @@ class _Slot:
 
 
 class PredictionPipeline:
-    def __init__(self, model, n_streams=4, use_graphs=None):
+    def __init__(self, model, n_streams=8, use_graphs=None):
         self.model = model
         dev = next(model.parameters()).device
         if dev.type != 'cuda':

@@ -198,7 +198,7 @@ class Trainer(object):
             raise ValueError('eval batch size %d is not divisible by %d ranks' % (eb, self.world))
         sl = cdist.shard_slice(eb, self.rank, self.world)
         # the calls are independent: their kernel chains overlap on a few HIP streams (cmvae_amd/pipeline.py)
-        pipe = PredictionPipeline(self.model, getattr(a, 'eval_streams', None) or 4)
+        pipe = PredictionPipeline(self.model, getattr(a, 'eval_streams', None) or 8)
         targets = []
         for _ in range(max(1, -(-a.eval_episodes // eb))):
             X_tr, y_tr, X_te, y_te = self.data.generate_test_episode(way=a.way, shot=shot, query=a.query,
