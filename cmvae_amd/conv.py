@@ -121,7 +121,8 @@ _ws_cache = {}
 
 def _wgrad_ws(rows, device):
     nbytes = lib.cmvae_conv_wgrad_workspace_bytes(rows)
-    key = (device, 'wgrad')
+    # one workspace per (device, stream): launches on different streams may be in flight together
+    key = (device, 'wgrad', _stream())
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -10,6 +10,8 @@ Pre-BatchNorm activations y1..y3 are the only tensors kept for the backward pass
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import conv
@@ -108,6 +110,19 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
     return y, (colsum(part) if want_stats else None)
 
 
+# CMVAE_BN_SIDE=1: the decoder's BatchNorm backward passes on a side stream next to the weight-gradient GEMMs (off by
+# default: measured slower inside the step, see _DecoderBCE.backward)
+BN_SIDE_STREAM = os.environ.get('CMVAE_BN_SIDE', '0') not in ('', '0')
+_side = {}
+
+
+def _side_stream(device):
+    s = _side.get(device)
+    if s is None:
+        s = _side[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 class _DecoderBCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h_rec, target, M, training, bns, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3, w4, b4):
@@ -164,20 +179,42 @@ class _DecoderBCE(torch.autograd.Function):
         db4 = tot[1152:1153]
         sums = tot[1024:1152]
         grads_w, grads_b, grads_g, grads_be = [None] * 3, [None] * 3, [None] * 3, [None] * 3
-        masked = True
+        # Per layer: data gradient, BatchNorm backward of the layer below (sums, finalize, apply), weight gradient.
+        # CMVAE_BN_SIDE=1 puts the memory-bound BatchNorm passes on a side stream in the shadow of the weight-gradient
+        # GEMMs.  In isolation half of such a pass hides behind them (tools/probe_overlap.py: 3.18 -> 2.62 ms for four
+        # passes next to four layer-3 launches); inside the step the fork / join events and the slower GEMMs cost more
+        # than the two short passes give back (14.1 -> 14.5 ms/step), and the weight gradients next to the whole
+        # data-gradient chain are worse (14.8: two GEMMs side by side evict each other's operand rows).  Off by default.
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if BN_SIDE_STREAM else None
+        c1, c2, dgamma, dbeta = bn_bwd_finalize(sums, acts[3].shape[0])
+        # pass 2 of the last layer's backward writes dy3 directly
+        check(lib.cmvae_dec_out_bwd_apply(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
+                                          _p(g_loss), 1.0, _p(c1), _p(c2), _p(d), _stream()), 'cmvae_dec_out_bwd_apply')
+        grads_g[2], grads_be[2] = dgamma, dbeta
+        dy = d
         for li in (2, 1, 0):
             k, Hi = _LAYERS[li]
-            y, fold, x_in, fold_in = acts[li + 1], folds[li + 1], acts[li], folds[li]
-            c1, c2, dgamma, dbeta = bn_bwd_finalize(sums, y.shape[0])
-            if li == 2:
-                # pass 2 of the last layer's backward writes dy3 directly
-                check(lib.cmvae_dec_out_bwd_apply(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
-                                                  _p(g_loss), 1.0, _p(c1), _p(c2), _p(d), _stream()),
-                      'cmvae_dec_out_bwd_apply')
-                dy = d
-            else:
-                dy = bn_relu_bwd_apply(d, y, fold, c1, c2, masked, out=d)             # in place
-            grads_g[li], grads_be[li] = dgamma, dbeta
+            x_in, fold_in = acts[li], folds[li]
+            gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=PIXEL_MAJOR)
+            wtd = ws[li].detach().permute(2, 3, 0, 1).contiguous()   # [ky][kx][ci][co]
+            d_in = torch.empty(n * Hi * Hi, 64, device=dev)
+            conv.conv_gemm(gd, dy, wtd, d_in)
+            dy_below = None
+            if li > 0:
+                def bn_below():
+                    sums_b = bn_relu_bwd_sums(d_in, x_in, fold_in, masked=False)
+                    c1b, c2b, dg, dbe = bn_bwd_finalize(sums_b, x_in.shape[0])
+                    grads_g[li - 1], grads_be[li - 1] = dg, dbe
+                    return bn_relu_bwd_apply(d_in, x_in, fold_in, c1b, c2b, False, out=d_in)     # in place
+                if side is None:
+                    dy_below = bn_below()
+                else:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        dy_below = bn_below()
+                    for t in (grads_g[li - 1], grads_be[li - 1]):
+                        t.record_stream(main)
             dW = torch.empty_like(ws[li])
             db = torch.empty(64, device=dev)
             sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
@@ -189,14 +226,9 @@ class _DecoderBCE(torch.autograd.Function):
                                     accumulate_db=not first, a_scale=sc, a_shift=sh)
                     first = False
             grads_w[li], grads_b[li] = dW, db
-            gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=PIXEL_MAJOR)
-            wtd = ws[li].detach().permute(2, 3, 0, 1).contiguous()   # [ky][kx][ci][co]
-            d_in = torch.empty(n * Hi * Hi, 64, device=dev)
-            conv.conv_gemm(gd, dy, wtd, d_in)
-            d = d_in
-            if li > 0:
-                sums = bn_relu_bwd_sums(d, x_in, fold_in, masked=False)
-                masked = False
+            if side is not None and li > 0:
+                main.wait_stream(side)
+            d, dy = d_in, dy_below
         d_h = d.reshape(n, 256)
         return (d_h, None, None, None, None,
                 grads_w[0], grads_b[0], grads_g[0], grads_be[0],
