@@ -346,6 +346,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='o20')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph-step', choices=('auto', 'on', 'off'), default='auto',
+                    help='training step replayed from a HIP graph (auto: feature configs on one GPU, as Trainer does)')
     ap.add_argument('--eval-calls', type=int, default=40)
     ap.add_argument('--eval-streams', type=int, default=8,
                     help='HIP streams the independent prediction calls are dealt to, as Trainer.eval does (1 = sequential)')
@@ -403,7 +405,7 @@ def main():
            'dtype': 'f32', 'data': 'synthetic', 'rccl_ranks': ranks_seen,
            'config': {'workload': cfg['workload'], 'name': args.config, 'global_batch_episodes': Bl * world,
                       'parallelism': 'dp%d' % world}}
-    step = None
+    step = eager_step = None
     if not cfg.get('eval_only'):
         # synthetic meta-batches, resident in HBM before the timed region; each rank owns its shard
         n_pool = 4
@@ -411,7 +413,21 @@ def main():
                 for i in range(n_pool)]
         seeds = cdist.SeedUploader((Bl, way), device)
 
+        # what Trainer does (--graph-step auto): the feature models' step, bound by the host's launch rate when issued
+        # eagerly, is replayed from a HIP graph in a single process; the Omniglot step stays eager
+        graphed = None
+        if args.graph_step == 'on' or (args.graph_step == 'auto' and cfg['variant'] != 'omniglot' and world == 1):
+            from cmvae_amd.graph_step import GraphedStep
+            graphed = GraphedStep(model, flat, opt) if world == 1 else None
+        out['config']['graph_step'] = graphed is not None
+
         def step(i):
+            if graphed is not None:
+                idx = seeds.upload(cdist.draw_em_init(N, way, Bl * world, rank, world))
+                return graphed(pool[i % n_pool], idx, h_lambda, h_c, a_lambda)[:3]
+            return eager_step(i)
+
+        def eager_step(i):
             model.train()
             flat.zero()
             X = pool[i % n_pool]
@@ -490,7 +506,8 @@ def main():
     # roofline of the dominant kernel: one extra, untimed, instrumented training step (all ranks take part: the step
     # contains the BatchNorm-statistics and gradient all-reduces); the sweep config reports the EM pass
     if step is not None:
-        roof = roofline_conv_gemm(lambda: step(0)) if cfg['variant'] == 'omniglot' else roofline_linear(lambda: step(0))
+        roof = roofline_conv_gemm(lambda: eager_step(0)) if cfg['variant'] == 'omniglot' else \
+            roofline_linear(lambda: eager_step(0))      # launch by launch: the eager step, also where the step is replayed
     else:
         roof = None
     if rank == 0:

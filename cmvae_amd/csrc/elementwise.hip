@@ -377,6 +377,31 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
     }
 }
 
+// the same update with the step count read from device memory (the launch can be replayed from a HIP graph: the caller
+// increments *step_dev before every replay); bias corrections in double like the host does for adam_kernel
+__global__ __launch_bounds__(256) void adam_devstep_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                           float4* __restrict__ m, float4* __restrict__ v, long n4,
+                                                           const long long* __restrict__ step_dev, float lr, float b1,
+                                                           float b2, float eps, float wd) {
+    const double t = (double)step_dev[0];
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step = lr / bc1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        float4 pp = p[e], gg = g[e], mm = m[e], vv = v[e];
+#define CMVAE_ADAM1(c)                                                   \
+        {                                                                \
+            const float gr = fmaf(wd, pp.c, gg.c);                       \
+            mm.c = fmaf(b1, mm.c, (1.f - b1) * gr);                      \
+            vv.c = fmaf(b2, vv.c, (1.f - b2) * gr * gr);                 \
+            pp.c -= step * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));      \
+        }
+        CMVAE_ADAM1(x) CMVAE_ADAM1(y) CMVAE_ADAM1(z) CMVAE_ADAM1(w)
+#undef CMVAE_ADAM1
+        p[e] = pp; m[e] = mm; v[e] = vv;
+    }
+}
+
 static int grid_for(long n, int per_block) {
     long b = (n + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -450,4 +475,17 @@ extern "C" int cmvae_adam_step(float* param, const float* grad, float* exp_avg, 
                        (const float4*)grad, (float4*)exp_avg, (float4*)exp_avg_sq, n / 4, lr, beta1, beta2, eps,
                        weight_decay, (float)bc1, (float)sqrt(bc2));
     return check_launch("adam_kernel");
+}
+
+extern "C" int cmvae_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const int64_t* step_dev, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev && n >= 0 && n % 4 == 0,
+                  "cmvae_adam_step_dev: bad arguments (n must be a multiple of 4)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cmvae::adam_devstep_kernel, dim3(cmvae::grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float4*)param, (const float4*)grad, (float4*)exp_avg, (float4*)exp_avg_sq, n / 4,
+                       (const long long*)step_dev, lr, beta1, beta2, eps, weight_decay);
+    return cmvae::check_launch("adam_devstep_kernel");
 }

@@ -248,10 +248,24 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.t = 0
+        self.step_dev = None          # device-side step count: set by device_step(), for steps replayed from a HIP graph
+
+    def device_step(self):
+        """Keep the step count on the device from now on (the update launch then holds no per-step host value and can
+        be captured into a HIP graph and replayed); idempotent."""
+        if self.step_dev is None:
+            self.step_dev = torch.full((1,), self.t, dtype=torch.int64, device=self.flat.device)
+        return self
 
     def step(self):
-        self.t += 1
         n = self.flat.numel()
+        if self.step_dev is not None:
+            self.step_dev += 1
+            check(lib.cmvae_adam_step_dev(_p(self.flat), _p(self.flat_grads.flat), _p(self.exp_avg), _p(self.exp_avg_sq),
+                                          n, _p(self.step_dev), self.lr, self.betas[0], self.betas[1], self.eps,
+                                          self.weight_decay, _stream()), 'cmvae_adam_step_dev')
+            return
+        self.t += 1
         check(lib.cmvae_adam_step(_p(self.flat), _p(self.flat_grads.flat), _p(self.exp_avg), _p(self.exp_avg_sq), n,
                                   self.t, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                   _stream()), 'cmvae_adam_step')
@@ -260,9 +274,12 @@ class FlatAdam:
         self.flat_grads.zero()
 
     def state_dict(self):
-        return {'step': self.t, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
+        t = self.t if self.step_dev is None else int(self.step_dev)
+        return {'step': t, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
 
     def load_state_dict(self, sd):
         self.t = int(sd['step'])
+        if self.step_dev is not None:
+            self.step_dev.fill_(self.t)
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])

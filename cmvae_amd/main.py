@@ -40,6 +40,9 @@ def build_parser(variant):
     p.add_argument('--dual-ascent', action='store_true',
                    help='run the augmented-Lagrangian schedule on (h_lambda, h_c) after every epoch: the block the '
                         'reference carries commented out (omniglot/trainer.py:171-177); off = the reference\'s live code')
+    p.add_argument('--graph-step', choices=('auto', 'on', 'off'), default='auto',
+                   help='replay the training step from a HIP graph (new; auto: the feature variants in a single '
+                        'process, whose step is bound by the host\'s launch rate; same arithmetic as the eager step)')
     p.add_argument('--eval-streams', type=int, default=8,
                    help='HIP streams the independent prediction calls of an evaluation are dealt to (new; 1 = the '
                         'reference\'s sequential loop, same results)')

@@ -20,7 +20,9 @@ import numpy as np
 import torch
 
 from . import dist as cdist
+from . import ops
 from .data import EpisodeData, TrainStream
+from .graph_step import GraphedStep
 from .linear import FlatAdam
 from .model import OmniglotGMVAE, FeatureGMVAE
 from .pipeline import PredictionPipeline
@@ -68,6 +70,7 @@ class Trainer(object):
         self.flat = cdist.FlatGrads(self.model.parameters()).overlap_tail(self.model.tail_param_count())
         self.optimizer = FlatAdam(self.flat, lr=args.lr, weight_decay=args.weight_decay)
         self.seeds = cdist.SeedUploader((self.local_batch, args.way), self.device)
+        self._graphed = None
         self.log_interval = max(1, int(getattr(args, 'log_interval', 50)))
         self.best_files = {}
         self.log_path = os.path.join(args.save_dir, 'train_log.jsonl')
@@ -104,11 +107,23 @@ class Trainer(object):
             # every rank holds the same generator state: draw the global noise and keep this rank's episodes
             eps = cdist.draw_eps(a.batch_size, a.sample_size, a.train_mc_sample_size, a.latent_size, self.device,
                                  self.rank, self.world)
+        if self._use_graph_step():
+            if self._graphed is None:
+                self._graphed = GraphedStep(self.model, self.flat, self.optimizer)
+            return self._graphed(X.contiguous(), idx, h_lambda, h_c, a_lambda)
         X_rec, rec_loss, kl_loss, h_augment, h = self.model(X, h_lambda, h_c, a_lambda, eps=eps, init_idx=idx)
         (rec_loss + kl_loss + h_augment).backward()
         self.flat.allreduce()
         self.optimizer.step()
         return rec_loss, kl_loss, h_augment, h
+
+    def _use_graph_step(self):
+        """--graph-step auto: the feature variants in a single process (their step is bound by the host's launch rate;
+        the Omniglot step is bound by its kernels: cmvae_amd/graph_step.py); on / off force it."""
+        mode = getattr(self.args, 'graph_step', 'auto')
+        if mode == 'off' or self.world > 1 or getattr(self.args, 'debug', False) or ops.CHECK_INDICES:
+            return False
+        return mode == 'on' or self.variant != 'omniglot'
 
     def train(self):
         a, spec = self.args, VARIANTS[self.variant]
@@ -164,6 +179,7 @@ class Trainer(object):
         self.model.load_state_dict(state['state_dict'])
         self.flat = cdist.FlatGrads(self.model.parameters()).overlap_tail(self.model.tail_param_count())
         self.optimizer = FlatAdam(self.flat, lr=self.args.lr, weight_decay=self.args.weight_decay)
+        self._graphed = None                     # graphs of the previous model's buffers are void
         if resume_optimizer and 'optimizer' in state:
             self.optimizer.load_state_dict(state['optimizer'])
         return state

@@ -242,6 +242,11 @@ int cmvae_causal_lc_bwd(const float* d_eps, const float* hid, const float* w2, i
  * omniglot/trainer.py:48-52); step counts from 1; n % 4 == 0.                                               */
 int cmvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* The same update with the step count (>= 1) read from device memory at run time: a launch that is replayed from a
+ * HIP graph (the caller increments *step_dev before each replay).                                              */
+int cmvae_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const int64_t* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        void* stream);
 
 /* ==== BatchNorm (training statistics over the whole meta-batch) on channels-last [rows,64]
  * nn.BatchNorm2d after every conv (omniglot/module.py:15,20,25,30,51,55,59).  The conv GEMM

@@ -127,3 +127,54 @@ def test_prediction_pipeline_equals_sequential_calls(device):
     import pytest
     with pytest.raises(RuntimeError):
         PredictionPipeline(model, 2)
+
+
+def test_graphed_step_equals_eager_step(device):
+    """cmvae_amd/graph_step.py: the feature-model training step replayed from a HIP graph walks the eager step's
+    trajectory — same noise realisation (drawn by the same generator call outside the graph), same kernels, and Adam's
+    bias corrections from the device-side step count: parameters after 8 steps agree to fp32 rounding of the two Adam
+    entry points, losses step by step."""
+    import copy
+    import numpy as np
+    import torch
+    from cmvae_amd import dist as cdist
+    from cmvae_amd.graph_step import GraphedStep
+    from cmvae_amd.linear import FlatAdam
+    from cmvae_amd.model import FeatureGMVAE
+    torch.manual_seed(4)
+    B, S, M, K, Fd = 4, 5, 16, 5, 256
+    m1 = FeatureGMVAE(input_shape=Fd, component_size=K, train_mc_sample_size=M, test_mc_sample_size=M,
+                      unsupervised_em_iters=3, semisupervised_em_iters=3).to(device)
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(9)
+    batches = [torch.relu(torch.randn(B, S, Fd, generator=g)).to(device) for _ in range(8)]
+    rng = np.random.RandomState(3)
+    seeds = [torch.from_numpy(np.stack([rng.choice(S * M, K, replace=False) for _ in range(B)])).to(device)
+             for _ in range(8)]
+    consts = (0.1, 0.1, 1e-3)
+
+    f1 = cdist.FlatGrads(m1.parameters()); o1 = FlatAdam(f1, lr=1e-3, weight_decay=5e-5)
+    torch.manual_seed(11)
+    eager = []
+    for X, idx in zip(batches, seeds):
+        m1.train(); f1.zero()
+        _, rec, kl, ha, h = m1(X, *consts, init_idx=idx)
+        (rec + kl + ha).backward(); f1.allreduce(); o1.step()
+        eager.append([float(t.detach()) for t in (rec, kl, ha, h)])
+
+    f2 = cdist.FlatGrads(m2.parameters()); o2 = FlatAdam(f2, lr=1e-3, weight_decay=5e-5)
+    stepper = GraphedStep(m2, f2, o2)
+    torch.manual_seed(11)
+    replayed = []
+    for X, idx in zip(batches, seeds):
+        replayed.append([float(t) for t in stepper(X, idx, *consts)])
+    assert stepper.calls == 8 and len(stepper.graphs) == 1
+    for a, b in zip(eager, replayed):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-5 * max(abs(x), 1e-3), (a, b)
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        assert float((p1 - p2).detach().abs().max()) <= 2e-5 * float(p1.detach().abs().max()) + 1e-7
+    assert o2.state_dict()['step'] == 8 and o1.state_dict()['step'] == 8
+    # other loss constants: a second graph, no new warm-up
+    stepper(batches[0], seeds[0], 0.2, 0.1, 1e-3)
+    assert len(stepper.graphs) == 2
