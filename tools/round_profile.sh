@@ -8,7 +8,7 @@ T=$1_$CFG
 # --- PMC traffic (two passes, one counter each)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --eval-calls 2 --eval-streams 1 > /tmp/pmc_$c.log 2>&1 || { echo "pass $c failed"; tail -5 /tmp/pmc_$c.log; exit 1; }
+  timeout -s KILL 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --eval-calls 2 --eval-streams 1 --graph-step off > /tmp/pmc_$c.log 2>&1 || { echo "pass $c failed"; tail -5 /tmp/pmc_$c.log; exit 1; }
   echo "pass $c done"
 done
 python - "$T" <<'PY'
@@ -46,7 +46,7 @@ for k, d in sorted(res['kernels'].items(), key=lambda kv: -kv[1]['hbm_bytes_per_
 PY
 # --- kernel stats
 rm -rf /tmp/profs
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs -- python bench.py --config $CFG --steps 20 --warmup 3 --no-cpu-baseline --eval-calls 4 --eval-streams 1 > gpurun_out/${T}_bench_profiled.json 2> gpurun_out/${T}_bench_profiled.err || { tail -5 gpurun_out/${T}_bench_profiled.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs -- python bench.py --config $CFG --steps 20 --warmup 3 --no-cpu-baseline --eval-calls 4 --eval-streams 1 --graph-step off > gpurun_out/${T}_bench_profiled.json 2> gpurun_out/${T}_bench_profiled.err || { tail -5 gpurun_out/${T}_bench_profiled.err; exit 1; }
 cp /tmp/profs/*/*kernel_stats.csv gpurun_out/${T}_kernel_stats.csv
 # --- the default bench line (reads the traffic file committed under profiles/, so copy first)
 mkdir -p profiles && cp gpurun_out/${T}_pmc_traffic.json profiles/${T}_pmc_traffic.json
