@@ -1000,6 +1000,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(ConvGeom g, int tap0
 // flight per wave (loads of chunk c+1 are issued as chunk c's groups are consumed).  The waves of a workgroup split
 // into tap pairs x row streams and add their accumulators through LDS once, at the end.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+#if CMVAE_ABLATE == 20
+__device__ long long g_clock_probe[2];
+#endif
 
 struct ChunkDesc {            // all uniform (SGPRs): the per-lane part of every address is a kernel-wide constant
     int a[2];                 // element offsets of the two taps' operand rows (image 16*ib, group 0)
@@ -1129,6 +1132,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
     int ib = c / npix;
     int y, x;
     { const int pix = c - ib * npix; y = pix / g.Wg; x = pix - y * g.Wg; }
+#if CMVAE_ABLATE == 20      // shader clock during this kernel: clock64 ticks per 100 MHz wall tick, seen by one wave
+    const long long clk0 = clock64(), wall0 = wall_clock64();
+#endif
 #if CMVAE_STAGGER
     // the two workgroups of a CU start half a chunk apart, so that one's address / descriptor work falls into the
     // other's MFMA phase instead of both alternating in lock step
@@ -1150,6 +1156,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
         cur = nxt;
     }
 
+#if CMVAE_ABLATE == 20
+    if (blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+        g_clock_probe[0] = clock64() - clk0; g_clock_probe[1] = wall_clock64() - wall0;
+    }
+#endif
     // add the row streams of a tap pair (wave p == 0 keeps the sum): lane-major LDS image of the 128 accumulators
     float* cb = comb + tp * 8192 + lane;
     for (int k = 1; k < P; ++k) {
@@ -1592,3 +1603,9 @@ extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, con
     }
     return 0;
 }
+
+#if CMVAE_ABLATE == 20
+extern "C" int cmvae_debug_clock_probe(long long* out2) {
+    return hipMemcpyFromSymbol(out2, HIP_SYMBOL(cmvae::g_clock_probe), 16) == hipSuccess ? 0 : -1;
+}
+#endif
