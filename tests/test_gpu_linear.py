@@ -187,3 +187,42 @@ def test_center_rows(B, N):
     yd = center_rows(xd)
     yd.backward(go.cuda())
     assert _rel(yd, yr) < 1e-6 and _rel(xd.grad, xr.grad) < 1e-6
+
+
+def test_adam_device_step_equals_host_step():
+    """cmvae_adam_step_dev (step count read from device memory, replayable from a HIP graph) walks the trajectory of
+    cmvae_adam_step and of torch.optim.Adam: bias corrections computed in double on both sides."""
+    from cmvae_amd.dist import FlatGrads
+    from cmvae_amd.linear import FlatAdam
+    g = torch.Generator().manual_seed(12)
+    w0 = [torch.randn(37, 64, generator=g), torch.randn(129, generator=g)]
+    grads = [[torch.randn(37, 64, generator=g), torch.randn(129, generator=g)] for _ in range(6)]
+    pt = [torch.nn.Parameter(t.clone()) for t in w0]
+    ref = torch.optim.Adam(pt, lr=3e-3, weight_decay=1e-4)
+    runs = []
+    for dev_step in (False, True):
+        ps = [torch.nn.Parameter(t.clone().cuda()) for t in w0]
+        flat = FlatGrads(ps)
+        opt = FlatAdam(flat, lr=3e-3, weight_decay=1e-4)
+        if dev_step:
+            opt.device_step()
+        for gs in grads:
+            flat.zero()
+            for p, gr in zip(ps, gs):
+                p.grad = gr.cuda()
+            flat.allreduce()
+            opt.step()
+        assert opt.state_dict()['step'] == 6
+        runs.append([p.detach().cpu() for p in ps])
+    for gs in grads:
+        for p, gr in zip(pt, gs):
+            p.grad = gr.clone()
+        ref.step()
+    for a, b, r in zip(runs[0], runs[1], pt):
+        assert torch.equal(a, b)
+        assert float((a - r.detach()).abs().max()) < 2e-6
+    # a checkpointed step count survives the switch to the device-side counter
+    ps = [torch.nn.Parameter(t.clone().cuda()) for t in w0]
+    opt = FlatAdam(FlatGrads(ps), lr=1e-3).device_step()
+    opt.load_state_dict({'step': 41, 'exp_avg': torch.zeros_like(opt.exp_avg), 'exp_avg_sq': torch.zeros_like(opt.exp_avg_sq)})
+    assert opt.state_dict()['step'] == 41
