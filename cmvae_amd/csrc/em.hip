@@ -42,14 +42,24 @@ __device__ __forceinline__ void causal_row(const float* xs, float* es, const cmv
     const int q = lane & 15;     // which float4 of the 64-wide fc1 row
     const int sub = lane >> 4;   // which of the 4 hidden units of a 1-KiB packet
     const float4 xv = reinterpret_cast<const float4*>(xs)[q];
+    // every load of a pair of outputs is requested before the first is used (the kernels that call this are chains of
+    // L2 round trips: 16 weight packets and their bias / output-weight scalars in flight per lane)
 #pragma unroll 2
     for (int jj = 0; jj < 64 / NW; ++jj) {
         const int j = (64 / NW) * w + jj;
         float acc = 0.f;
+        float4 wvs[8];
+        float b1s[8], w2s[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int u = 32 * j + 4 * it + sub;
-            const float4 wv = reinterpret_cast<const float4*>(c.W + (size_t)u * D)[q];
+            wvs[it] = reinterpret_cast<const float4*>(c.W + (size_t)u * D)[q];
+            b1s[it] = c.b1[u];
+            w2s[it] = c.w2[u];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const float4 wv = wvs[it];
             float p = wv.x * xv.x;
             p = fmaf(wv.y, xv.y, p);
             p = fmaf(wv.z, xv.z, p);
@@ -58,7 +68,7 @@ __device__ __forceinline__ void causal_row(const float* xs, float* es, const cmv
             p += __shfl_xor(p, 2);
             p += __shfl_xor(p, 4);
             p += __shfl_xor(p, 8);
-            acc = fmaf(elu_f(p + c.b1[u]), c.w2[u], acc);
+            acc = fmaf(elu_f(p + b1s[it]), w2s[it], acc);
         }
         acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
@@ -611,18 +621,45 @@ __global__ __launch_bounds__(1024) void em_finalize_kernel(FinArgs a) {
     } else {
         // ---- N_k' for every component (needed for pi), fixed-order reduction
         {
+            // (loads four partials ahead: a loop of dependent load -> add round trips to L2 is what this kernel's time
+            // was made of; the summation order is unchanged)
             const int kk = tid & 31, ch = tid >> 5;   // 32 chunks of blocks
             float acc = 0.f;
-            for (int i = ch; i < a.nblk; i += 32) acc += a.part_N[((size_t)b * a.nblk + i) * 32 + kk];
+            const float* pn = a.part_N + (size_t)b * a.nblk * 32 + kk;
+            int i = ch;
+            for (; i + 96 < a.nblk; i += 128) {
+                const float v0 = pn[(size_t)i * 32], v1 = pn[(size_t)(i + 32) * 32], v2 = pn[(size_t)(i + 64) * 32],
+                            v3 = pn[(size_t)(i + 96) * 32];
+                acc += v0; acc += v1; acc += v2; acc += v3;
+            }
+            for (; i < a.nblk; i += 32) acc += pn[(size_t)i * 32];
             nred[ch * 32 + kk] = acc;
         }
         // ---- S1 (and S2) for this component
         {
             float acc = 0.f, acc2 = 0.f;
-            for (int i = w; i < a.nblk; i += FW) {
-                const size_t o = (((size_t)b * a.nblk + i) * K + k) * D + lane;
-                acc += a.part_S1[o];
-                if (a.part_S2) acc2 += a.part_S2[o];
+            const size_t st = (size_t)K * D;                       // partials of consecutive blocks
+            const size_t o0 = ((size_t)b * a.nblk * K + k) * D + lane;
+            int i = w;
+            if (a.part_S2) {
+                for (; i + 3 * FW < a.nblk; i += 4 * FW) {
+                    const size_t o = o0 + (size_t)i * st;
+                    const float v0 = a.part_S1[o], v1 = a.part_S1[o + FW * st], v2 = a.part_S1[o + 2 * FW * st],
+                                v3 = a.part_S1[o + 3 * FW * st];
+                    const float u0 = a.part_S2[o], u1 = a.part_S2[o + FW * st], u2 = a.part_S2[o + 2 * FW * st],
+                                u3 = a.part_S2[o + 3 * FW * st];
+                    acc += v0; acc += v1; acc += v2; acc += v3;
+                    acc2 += u0; acc2 += u1; acc2 += u2; acc2 += u3;
+                }
+                for (; i < a.nblk; i += FW) { acc += a.part_S1[o0 + (size_t)i * st]; acc2 += a.part_S2[o0 + (size_t)i * st]; }
+            } else {
+                for (; i + 3 * FW < a.nblk; i += 4 * FW) {
+                    const size_t o = o0 + (size_t)i * st;
+                    const float v0 = a.part_S1[o], v1 = a.part_S1[o + FW * st], v2 = a.part_S1[o + 2 * FW * st],
+                                v3 = a.part_S1[o + 3 * FW * st];
+                    acc += v0; acc += v1; acc += v2; acc += v3;
+                }
+                for (; i < a.nblk; i += FW) acc += a.part_S1[o0 + (size_t)i * st];
             }
             red[w * D + lane] = acc;
             red2[w * D + lane] = acc2;
