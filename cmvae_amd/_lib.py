@@ -94,10 +94,16 @@ SIGNATURES = {
     'cmvae_conv_gemm_grid': (c_int, [c_int, c_int]),
     'cmvae_conv_gemm': (c_int, [_PG, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p]),
+    'cmvae_conv_gemm_multi_grid': (c_int, []),
+    'cmvae_conv_gemm_multi': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
     'cmvae_conv_wgrad_workspace_bytes': (c_size_t, [c_int]),
     'cmvae_conv_wgrad': (c_int, [_PG, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  ctypes.POINTER(c_int64), c_int64, c_int64, c_void_p, c_void_p, c_int,
                                  c_void_p, c_size_t, c_void_p]),
+    'cmvae_conv_wgrad_multi': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       ctypes.POINTER(c_int64), c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     'cmvae_linear_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                  c_void_p]),
     'cmvae_linear_mse_partials': (c_int, [c_int, c_int]),

@@ -116,6 +116,21 @@ def conv_gemm(g, A, Wt, out, bias=None, a_scale=None, a_shift=None, act=0, n_col
     return part
 
 
+@functools.lru_cache(maxsize=None)
+def gemm_multi_grid():
+    return lib.cmvae_conv_gemm_multi_grid()
+
+
+def conv_gemm_multi(geoms, A, Wt, out, bias=None, a_scale=None, a_shift=None, stats=False):
+    """Up to four geometries (the sub-pixel phases of a transposed conv) over the same tensors in one launch.
+    Returns the partial statistics [gemm_multi_grid(),128] over all geometries' rows if asked."""
+    arr = (ConvGeom * len(geoms))(*geoms)
+    part = torch.empty(gemm_multi_grid(), 128, device=A.device, dtype=torch.float32) if stats else None
+    check(lib.cmvae_conv_gemm_multi(arr, len(geoms), _p(A), _p(Wt), _p(bias), _p(a_scale), _p(a_shift), _p(out),
+                                    _p(part), _stream()), 'cmvae_conv_gemm_multi')
+    return part
+
+
 _ws_cache = {}
 
 
@@ -137,3 +152,14 @@ def conv_wgrad(g, A, G, dW, tap_off, s_ci, s_co, db=None, accumulate_db=False, a
     check(lib.cmvae_conv_wgrad(ctypes.byref(g), _p(A), _p(a_scale), _p(a_shift), _p(G), g_pitch, g_col, offs,
                                s_ci, s_co, _p(dW), _p(db), int(accumulate_db), _p(ws), ws.numel(), _stream()),
           'cmvae_conv_wgrad')
+
+
+def conv_wgrad_multi(geoms, A, G, dW, tap_offs, s_ci, s_co, db=None, a_scale=None, a_shift=None, g_pitch=64):
+    """Weight (and bias) gradient of up to four geometries over the same tensors — the sub-pixel phases of a
+    transposed conv — in one launch + one reduction.  tap_offs: one list of dW tap offsets per geometry."""
+    ws = _wgrad_ws(geoms[0].rows_total, A.device)
+    arr = (ConvGeom * len(geoms))(*geoms)
+    flat = [t for offs in tap_offs for t in offs]
+    offs = (ctypes.c_int64 * len(flat))(*flat)
+    check(lib.cmvae_conv_wgrad_multi(arr, len(geoms), _p(A), _p(a_scale), _p(a_shift), _p(G), g_pitch, offs, s_ci,
+                                     s_co, _p(dW), _p(db), _p(ws), ws.numel(), _stream()), 'cmvae_conv_wgrad_multi')

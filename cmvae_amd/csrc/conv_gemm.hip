@@ -601,11 +601,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 //   NW = 8 waves, <= 9 taps (<= 157 KB, one workgroup per CU): 3x3 convolutions and their data gradients.
 // Taps tap0 .. tap0+ntaps-1 of the geometry.
 constexpr int WSTAT_TAPS4 = 4, WSTAT_TAPS8 = 9;
+// bid / nblk: the workgroup's index among the workgroups that share this geometry (a launch may run several
+// geometries side by side: conv_gemm_wstat_multi_kernel); stats_bid / stats_nblk: its index in the whole launch.
 template <int ACT, bool HAS_T, int NW, bool PM>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kernel(
-    ConvGeom g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
+__device__ __forceinline__ void wstat_body(
+    const ConvGeom& g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
-    float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps) {
+    float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps, int bid, int nblk, int nb_in, int stats_bid,
+    int stats_nblk) {
     constexpr int BMT = 32 * NW;                                   // rows per tile: 32 per wave
     extern __shared__ __align__(16) float wstat_smem[];
     float* Ws = wstat_smem;                                        // [ntaps][64][LDA]
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int q = tid & 15, rb = tid >> 4;
-    const int nb = blockIdx.y;
+    const int nb = nb_in;
     {
         const float* Wn = Wt + nb * g.w_nblk_stride + 4 * q;
         for (int t = 0; t < ntaps; ++t)
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
         for (int kk = 0; kk < 8; ++kk) ra[kk] = *reinterpret_cast<const float4*>(p + 8 * kk);
     };
     // one software pipeline over the workgroup's (tile, valid tap) steps; no block barrier inside
-    int tile = blockIdx.x;
+    int tile = bid;
     TileInfo ti = taps.tile<PM>(g, lane, tile * BMT, BMT, tap0, ntaps);
     unsigned mask = ti.mask;
     int t = first_tap(mask);
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
         int tn, ntile = tile;
         unsigned nmask = mask;
         if (last) {
-            ntile = tile + gridDim.x;
+            ntile = tile + nblk;
             ti = taps.tile<PM>(g, lane, ntile * BMT, BMT, tap0, ntaps);
             nmask = ti.mask;
             tn = first_tap(nmask);
@@ -799,12 +802,41 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kern
             float v = 0.f;
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) v += red[ww * 128 + tid];
-            stats_part[(long)blockIdx.x * 128 + tid] = v;
+            stats_part[(long)stats_bid * 128 + tid] = v;
             // the caller sized the partials for cmvae_conv_gemm_grid() workgroups: the rows this launch does not
             // own (it runs fewer, one or two per CU) are zeroed
-            for (int r = blockIdx.x + gridDim.x; r < stats_rows; r += gridDim.x) stats_part[(long)r * 128 + tid] = 0.f;
+            for (int r = stats_bid + stats_nblk; r < stats_rows; r += stats_nblk) stats_part[(long)r * 128 + tid] = 0.f;
         }
     }
+}
+
+template <int ACT, bool HAS_T, int NW, bool PM>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kernel(
+    ConvGeom g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
+    float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps) {
+    wstat_body<ACT, HAS_T, NW, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps,
+                                   (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Up to four geometries over the same operand, weight and output tensors in ONE launch — the sub-pixel phases of a
+// transposed convolution.  Every workgroup belongs to one geometry (begin[] partitions the grid in proportion to the
+// phases' tap work) and keeps that phase's <= 4 weight tiles in LDS.  One launch instead of four saves the fill, ramp
+// and drain of three launches, which is most of the time of the small layers' phases.
+struct ConvGeomMulti {
+    ConvGeom g[4];
+    int begin[5];
+};
+template <int ACT, bool HAS_T, bool PM>
+__global__ __launch_bounds__(256, 2) void conv_gemm_wstat_multi_kernel(
+    ConvGeomMulti p, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
+    float* __restrict__ stats_part, int stats_rows) {
+    const int b = blockIdx.x;
+    const int ph = (b >= p.begin[1]) + (b >= p.begin[2]) + (b >= p.begin[3]);          // uniform
+    const ConvGeom& g = p.g[ph];
+    wstat_body<ACT, HAS_T, 4, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, 0, g.ntaps,
+                                  b - p.begin[ph], p.begin[ph + 1] - p.begin[ph], 0, b, (int)gridDim.x);
 }
 
 template <int ACT, bool HAS_T, int NW, bool PM>
@@ -1011,33 +1043,25 @@ struct ChunkDesc {            // all uniform (SGPRs): the per-lane part of every
     unsigned valid;           // bit u = tap u inside the image, bit 2 = chunk inside the range
 };
 
+// bid / nblk: the workgroup's index among those that share this geometry, taps and gradient columns; part / db_part
+// point at that group's first partial (workgroup bid writes nt_stride tap blocks from part + bid * nt_stride * 4096).
 template <bool HAS_T>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, int tap0, int nt, int nimg,
-                                                                   const float* __restrict__ A,
-                                                                   const float* __restrict__ a_scale,
-                                                                   const float* __restrict__ a_shift,
-                                                                   const float* __restrict__ G, int g_pitch, int g_col,
-                                                                   float* __restrict__ part,
-                                                                   float* __restrict__ db_part) {
-    __shared__ __align__(16) float comb[2 * 128 * 64];
+__device__ __forceinline__ void wgrad_stream_body(const ConvGeom& g, int tap0, int nt, int nimg,
+                                                  const float* __restrict__ A, const float* __restrict__ a_scale,
+                                                  const float* __restrict__ a_shift, const float* __restrict__ G,
+                                                  int g_pitch, int g_col, float* __restrict__ part,
+                                                  float* __restrict__ db_part, int bid, int nblk, int nt_stride,
+                                                  float* comb) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kq = lane >> 4;
-    tap0 += nt * blockIdx.z;
-    g_col += 64 * blockIdx.y;
-    {
-        const long slot = (long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x;
-        part += slot * nt * 4096;
-        if (db_part) db_part += slot * 64;
-        if (blockIdx.z != 0) db_part = nullptr;
-    }
     const bool split = nt > 2;                                   // two tap pairs x two row streams, else four row streams
     const int tp = split ? (w & 1) : 0;
     const int p = split ? (w >> 1) : w;
     const int P = split ? 2 : 4;
     const int npix = g.Hg * g.Wg;
     const int nchunks = (nimg / 16) * npix;
-    const int nstreams = (int)gridDim.x * P, sid = (int)blockIdx.x * P + p;
+    const int nstreams = nblk * P, sid = bid * P + p;
     const int c_begin = (int)((long)nchunks * sid / nstreams), c_end = (int)((long)nchunks * (sid + 1) / nstreams);
     // the wave's taps within the launch group.  Four taps are a product set {a,b} x {c,d} of row and column offsets:
     // pairing (a,c) with (b,d) and (a,d) with (b,c) gives both pairs the same number of in-image positions (85 / 84 of
@@ -1138,7 +1162,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
 #if CMVAE_STAGGER
     // the two workgroups of a CU start half a chunk apart, so that one's address / descriptor work falls into the
     // other's MFMA phase instead of both alternating in lock step
-    if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(CMVAE_STAGGER);
+    if (bid >= nblk / 2) __builtin_amdgcn_s_sleep(CMVAE_STAGGER);
 #endif
     ChunkDesc cur = describe(ib, y, x, c < c_end);
 #pragma unroll
@@ -1157,7 +1181,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
     }
 
 #if CMVAE_ABLATE == 20
-    if (blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+    if (bid == 7 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
         g_clock_probe[0] = clock64() - clk0; g_clock_probe[1] = wall_clock64() - wall0;
     }
 #endif
@@ -1187,11 +1211,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
         if (tid < 64) {
             float sum = 0.f;
             for (int k = 0; k < P; ++k) sum += comb[k * 64 + tid];
-            db_part[(long)blockIdx.x * 64 + tid] = sum;
+            db_part[(long)bid * 64 + tid] = sum;
         }
     }
     if (p == 0) {
-        float* pb = part + (long)blockIdx.x * nt * 4096;
+        float* pb = part + (long)bid * nt_stride * 4096;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (t_u[u] >= nt) continue;
@@ -1205,6 +1229,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
                 }
         }
     }
+}
+
+template <bool HAS_T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, int tap0, int nt, int nimg,
+                                                                   const float* __restrict__ A,
+                                                                   const float* __restrict__ a_scale,
+                                                                   const float* __restrict__ a_shift,
+                                                                   const float* __restrict__ G, int g_pitch, int g_col,
+                                                                   float* __restrict__ part,
+                                                                   float* __restrict__ db_part) {
+    __shared__ __align__(16) float comb[2 * 128 * 64];
+    const long slot = (long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x;
+    wgrad_stream_body<HAS_T>(g, tap0 + nt * (int)blockIdx.z, nt, nimg, A, a_scale, a_shift, G, g_pitch,
+                             g_col + 64 * (int)blockIdx.y, part + slot * nt * 4096,
+                             (db_part && blockIdx.z == 0) ? db_part + slot * 64 : nullptr, (int)blockIdx.x,
+                             (int)gridDim.x, nt, comb);
+}
+
+// The sub-pixel phases of a transposed convolution (ConvGeomMulti, see conv_gemm_wstat_multi_kernel) in one launch:
+// workgroups begin[k] .. begin[k+1]-1 stream phase k's rows.  Every workgroup leaves 4 tap blocks of partials (a
+// phase with fewer taps leaves the rest unwritten and unread) and one bias-gradient partial: every phase covers
+// output pixels of its own, so the bias gradient is the sum over all of them.
+template <bool HAS_T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_stream_multi_kernel(ConvGeomMulti p, int nimg,
+                                                                         const float* __restrict__ A,
+                                                                         const float* __restrict__ a_scale,
+                                                                         const float* __restrict__ a_shift,
+                                                                         const float* __restrict__ G, int g_pitch,
+                                                                         float* __restrict__ part,
+                                                                         float* __restrict__ db_part) {
+    __shared__ __align__(16) float comb[2 * 128 * 64];
+    const int b = blockIdx.x;
+    const int ph = (b >= p.begin[1]) + (b >= p.begin[2]) + (b >= p.begin[3]);          // uniform
+    const ConvGeom& g = p.g[ph];
+    const int b0 = p.begin[ph];
+    wgrad_stream_body<HAS_T>(g, 0, g.ntaps, nimg, A, a_scale, a_shift, G, g_pitch, 0, part + (long)b0 * 4 * 4096,
+                             db_part ? db_part + (long)b0 * 64 : nullptr, b - b0, p.begin[ph + 1] - b0, 4, comb);
 }
 
 // out[y*y_stride + tap_off[NT*z + t] + ci*s_ci + co*s_co] = sum_blk part[(z,y)][blk][t][ci][co];
@@ -1257,6 +1318,56 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     } else {
         float* d = db + 64 * blockIdx.y;
         d[c] = accumulate_db ? d[c] + s : s;
+    }
+}
+
+// The same for a multi-phase launch: phase y's partials are those of workgroups begin[y] .. begin[y+1]-1 (4 tap blocks
+// each), its taps go to tap_off[4*y + t]; the bias gradient sums every workgroup's partial.
+struct WgradMultiOut {
+    long tap_off[16];
+    long s_ci, s_co;
+    int begin[5], ntaps[4];
+};
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const float* __restrict__ part, WgradMultiOut o,
+                                                                  float* __restrict__ dW,
+                                                                  const float* __restrict__ db_part,
+                                                                  float* __restrict__ db, int nblk_all) {
+    __shared__ float red[16 * 64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + c, ph = blockIdx.y;
+    const bool is_db = blockIdx.x == 4 * 64;
+    if (is_db ? (db == nullptr || ph != 0) : (e >> 12) >= o.ntaps[ph]) return;      // uniform per workgroup
+    float s0 = 0.f, s1 = 0.f;
+    if (!is_db) {
+        const int nblk = o.begin[ph + 1] - o.begin[ph];
+        const float* pp = part + (long)o.begin[ph] * 4 * 4096 + e;
+        int b = g;
+        for (; b + 112 < nblk; b += 128) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = pp[(long)(b + 16 * i) * 4 * 4096];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) { s0 += v[i]; s1 += v[i + 1]; }
+        }
+        for (; b + 16 < nblk; b += 32) {
+            s0 += pp[(long)b * 4 * 4096];
+            s1 += pp[(long)(b + 16) * 4 * 4096];
+        }
+        if (b < nblk) s0 += pp[(long)b * 4 * 4096];
+    } else {
+        for (int b = g; b < nblk_all; b += 16) s0 += db_part[(long)b * 64 + c];
+    }
+    red[g * 64 + c] = s0 + s1;
+    __syncthreads();
+    if (g != 0) return;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r * 64 + c];
+    if (!is_db) {
+        const int t = e >> 12, ci = (e >> 6) & 63, co = e & 63;
+        dW[o.tap_off[4 * ph + t] + ci * o.s_ci + co * o.s_co] = s;
+    } else {
+        db[c] = s;
     }
 }
 
@@ -1313,6 +1424,71 @@ static int wgrad_grid(int rows_total) {
 
 extern "C" int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks) {
     cmvae::clear_stale_error(); return gemm_grid(rows_total, n_col_blocks); }
+
+extern "C" int cmvae_conv_gemm_multi_grid(void) { cmvae::clear_stale_error(); return 2 * compute_units(); }
+
+extern "C" int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, const float* A, const float* Wt,
+                                     const float* bias, const float* a_scale, const float* a_shift, float* out,
+                                     float* stats_part, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(geoms && A && Wt && out, "cmvae_conv_gemm_multi: NULL argument");
+    CMVAE_REQUIRE(ngeom >= 1 && ngeom <= 4, "cmvae_conv_gemm_multi: %d geometries (1..4)", ngeom);
+    CMVAE_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "cmvae_conv_gemm_multi: scale and shift go together");
+    ConvGeomMulti p{};
+    long work[4] = {0, 0, 0, 0}, total_work = 0, total_tiles = 0;
+    int max_taps = 0;
+    for (int k = 0; k < ngeom; ++k) {
+        p.g[k] = to_geom(&geoms[k]);
+        const ConvGeom& g = p.g[k];
+        if (int e = check_geom(g)) return e;
+        CMVAE_REQUIRE(g.ntaps <= WSTAT_TAPS4, "cmvae_conv_gemm_multi: geometry %d has %d taps (at most %d)", k, g.ntaps,
+                      WSTAT_TAPS4);
+        CMVAE_REQUIRE(g.rows_total > 0 && g.o_pitch >= 64, "cmvae_conv_gemm_multi: geometry %d is empty", k);
+        CMVAE_REQUIRE((g.pm_nimg > 0) == (p.g[0].pm_nimg > 0), "cmvae_conv_gemm_multi: mixed row orders");
+        const long tiles = (g.rows_total + 127) / 128;
+        work[k] = tiles * g.ntaps;
+        total_work += work[k];
+        total_tiles += tiles;
+        if (g.ntaps > max_taps) max_taps = g.ntaps;
+    }
+    for (int k = ngeom; k < 4; ++k) p.g[k] = p.g[0];
+    // workgroups per geometry in proportion to its tap work, at least one, at most its tiles
+    int cap = 2 * compute_units();
+    if (total_tiles < cap) cap = (int)total_tiles;
+    if (cap < ngeom) cap = ngeom;
+    int nb[4] = {0, 0, 0, 0}, used = 0;
+    for (int k = 0; k < ngeom; ++k) {
+        long n = (long)cap * work[k] / total_work;
+        const long tiles = (p.g[k].rows_total + 127) / 128;
+        if (n < 1) n = 1;
+        if (n > tiles) n = tiles;
+        nb[k] = (int)n;
+        used += nb[k];
+    }
+    p.begin[0] = 0;
+    for (int k = 0; k < 4; ++k) p.begin[k + 1] = p.begin[k] + nb[k];
+    // (begin[k] of an unused geometry is the grid size: never reached)
+    const int stats_rows = 2 * compute_units();
+    const size_t lds = (size_t)max_taps * 64 * LDA * sizeof(float) + 2 * 4 * 32 * sizeof(int) + 4 * 128 * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const bool pm = p.g[0].pm_nimg > 0;
+#define CMVAE_MULTI(HAS_T, PM)                                                                                         \
+    do {                                                                                                               \
+        static const bool opted = [] {                                                                                 \
+            (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_multi_kernel<0, HAS_T, PM>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+            (void)hipGetLastError();                                                                                   \
+            return true;                                                                                               \
+        }();                                                                                                           \
+        (void)opted;                                                                                                   \
+        hipLaunchKernelGGL((conv_gemm_wstat_multi_kernel<0, HAS_T, PM>), dim3(used), dim3(256), lds, st, p, A, Wt,     \
+                           bias, a_scale, a_shift, out, stats_part, stats_rows);                                       \
+    } while (0)
+    if (a_scale) { if (pm) CMVAE_MULTI(true, true); else CMVAE_MULTI(true, false); }
+    else { if (pm) CMVAE_MULTI(false, true); else CMVAE_MULTI(false, false); }
+#undef CMVAE_MULTI
+    return check_launch("conv_gemm_wstat_multi_kernel");
+}
 
 extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, const float* Wt, const float* bias,
                                const float* a_scale, const float* a_shift, int act, int n_col_blocks, float* out,
@@ -1448,6 +1624,78 @@ extern "C" int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, con
     if (g.rows_total == 0) return 0;
     return wgrad_launch(g, A, a_scale, a_shift, G, g_pitch, g_col, tap_off_host, s_ci, s_co, dW, db, accumulate_db,
                         workspace, (hipStream_t)stream);
+}
+
+extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, const float* A, const float* a_scale,
+                                      const float* a_shift, const float* G, int g_pitch,
+                                      const int64_t* tap_off_host, int64_t s_ci, int64_t s_co, float* dW, float* db,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(geoms && A && G && tap_off_host && dW && workspace, "cmvae_conv_wgrad_multi: NULL argument");
+    CMVAE_REQUIRE(ngeom >= 1 && ngeom <= 4, "cmvae_conv_wgrad_multi: %d geometries (1..4)", ngeom);
+    CMVAE_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "cmvae_conv_wgrad_multi: scale and shift go together");
+    CMVAE_REQUIRE(g_pitch >= 64 && g_pitch % 4 == 0, "cmvae_conv_wgrad_multi: bad gradient pitch");
+    CMVAE_REQUIRE(workspace_bytes >= cmvae_conv_wgrad_workspace_bytes(0), "cmvae_conv_wgrad_multi: workspace too small");
+    ConvGeomMulti p{};
+    hipStream_t st = (hipStream_t)stream;
+    bool streamable = wgrad_stream_enabled();
+    int nimg = -1;
+    for (int k = 0; k < ngeom; ++k) {
+        p.g[k] = to_geom(&geoms[k]);
+        const ConvGeom& g = p.g[k];
+        if (int e = check_geom(g)) return e;
+        CMVAE_REQUIRE(g.ntaps <= 4, "cmvae_conv_wgrad_multi: geometry %d has %d taps (at most 4)", k, g.ntaps);
+        const int npix = g.Hg * g.Wg, ni = g.rows_total / npix;
+        if (nimg < 0) nimg = ni;
+        CMVAE_REQUIRE(ni == nimg && g.Ho == p.g[0].Ho && g.Wo == p.g[0].Wo && g.Hi == p.g[0].Hi && g.Wi == p.g[0].Wi &&
+                      g.a_pitch == p.g[0].a_pitch,
+                      "cmvae_conv_wgrad_multi: geometry %d is not over the same tensors as geometry 0", k);
+        streamable = streamable && ni > 0 && ni % 16 == 0 && (long)ni * g.Ho * g.Wo * g_pitch < (1L << 31);
+    }
+    if (nimg == 0) return 0;
+    if (!streamable) {        // image counts the streaming kernel does not take: one launch per geometry
+        const int64_t* to = tap_off_host;
+        for (int k = 0; k < ngeom; ++k) {
+            if (int e = wgrad_launch(p.g[k], A, a_scale, a_shift, G, g_pitch, 0, to, s_ci, s_co, dW, db, k > 0,
+                                     workspace, st)) return e;
+            to += p.g[k].ntaps;
+        }
+        return 0;
+    }
+    // workgroups per geometry in proportion to the time of one of its row streams: chunks / streams per workgroup,
+    // a lone tap costing about 0.6 of a pair
+    const int max_blocks = wgrad_grid(1 << 30);
+    double wsum = 0., wk[4] = {0., 0., 0., 0.};
+    long chunks[4] = {0, 0, 0, 0};
+    for (int k = 0; k < ngeom; ++k) {
+        const ConvGeom& g = p.g[k];
+        chunks[k] = (long)(nimg / 16) * g.Hg * g.Wg;
+        wk[k] = (double)chunks[k] / (g.ntaps > 2 ? 2 : 4) * (g.ntaps == 1 ? 0.6 : 1.0);
+        wsum += wk[k];
+    }
+    WgradMultiOut o{};
+    o.s_ci = s_ci; o.s_co = s_co;
+    int used = 0;
+    const int64_t* to = tap_off_host;
+    for (int k = 0; k <= 4; ++k) {
+        p.begin[k] = o.begin[k] = used;         // (of an unused geometry: the grid size, never reached)
+        if (k >= ngeom) { if (k < 4) p.g[k] = p.g[0]; continue; }
+        long n = (long)(max_blocks * wk[k] / wsum);
+        if (n > chunks[k]) n = chunks[k];
+        if (n < 1) n = 1;
+        used += (int)n;
+        o.ntaps[k] = p.g[k].ntaps;
+        for (int t = 0; t < p.g[k].ntaps; ++t) o.tap_off[4 * k + t] = *to++;
+    }
+    CMVAE_REQUIRE(used <= max_blocks, "cmvae_conv_wgrad_multi: %d workgroups exceed the workspace", used);
+    float* part = (float*)workspace;
+    float* db_part = (float*)((char*)workspace + align_up((size_t)max_blocks * 4 * 4096 * sizeof(float)));
+    float* dbp = db ? db_part : nullptr;
+    if (a_scale) hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<true>, dim3(used), dim3(256), 0, st, p, nimg, A, a_scale, a_shift, G, g_pitch, part, dbp);
+    else hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<false>, dim3(used), dim3(256), 0, st, p, nimg, A, a_scale, a_shift, G, g_pitch, part, dbp);
+    if (int e = check_launch("conv_wgrad_stream_multi_kernel")) return e;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(4 * 64 + 1, ngeom), dim3(1024), 0, st, part, o, dW, dbp, db, used);
+    return check_launch("wgrad_reduce_multi_kernel");
 }
 
 // ============================================================================ nn.Linear on the same kernels

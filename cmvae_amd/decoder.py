@@ -96,6 +96,11 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
     y = torch.empty(n * Ho * Ho, 64, device=x.device)
     wprep = weight.detach().permute(2, 3, 1, 0).contiguous()                 # [ky][kx][co][ci]: all k*k taps
     phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=PIXEL_MAJOR) for py in (0, 1) for px in (0, 1)]
+    sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
+    if MULTI_PHASE:                      # all four phases in one launch
+        part = conv.conv_gemm_multi([g for g, _ in phases], x, wprep, y, bias=bias.detach(), a_scale=sc, a_shift=sh,
+                                    stats=want_stats)
+        return y, (colsum(part) if want_stats else None)
     part = None
     if want_stats:
         grids = [conv.gemm_grid(g.rows_total, 1) for g, _ in phases]
@@ -109,6 +114,9 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
             off += grids[i]
     return y, (colsum(part) if want_stats else None)
 
+
+# CMVAE_CONV_MULTI=0: one launch per sub-pixel phase of a transposed conv instead of one per layer (A/B measurements)
+MULTI_PHASE = os.environ.get('CMVAE_CONV_MULTI', '1') not in ('', '0')
 
 # CMVAE_BN_SIDE=1: the decoder's BatchNorm backward passes on a side stream next to the weight-gradient GEMMs (off by
 # default: measured slower inside the step, see _DecoderBCE.backward)
@@ -218,13 +226,15 @@ class _DecoderBCE(torch.autograd.Function):
             dW = torch.empty_like(ws[li])
             db = torch.empty(64, device=dev)
             sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
-            first = True
-            for py in (0, 1):
-                for px in (0, 1):
-                    g, tap_idx = conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=PIXEL_MAJOR)
+            phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=PIXEL_MAJOR)
+                      for py in (0, 1) for px in (0, 1)]
+            if MULTI_PHASE:
+                conv.conv_wgrad_multi([g for g, _ in phases], x_in, dy, dW, [t for _, t in phases], s_ci=64 * k * k,
+                                      s_co=k * k, db=db, a_scale=sc, a_shift=sh)
+            else:
+                for i, (g, tap_idx) in enumerate(phases):
                     conv.conv_wgrad(g, x_in, dy, dW, tap_idx, s_ci=64 * k * k, s_co=k * k, db=db,
-                                    accumulate_db=not first, a_scale=sc, a_shift=sh)
-                    first = False
+                                    accumulate_db=i > 0, a_scale=sc, a_shift=sh)
             grads_w[li], grads_b[li] = dW, db
             if side is not None and li > 0:
                 main.wait_stream(side)

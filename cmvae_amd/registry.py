@@ -193,6 +193,38 @@ _d.define('conv_gemm(int[] geom, Tensor A, Tensor Wt, Tensor(a!) out, Tensor? bi
           'int act, int n_col_blocks, bool stats) -> Tensor')
 _d.define('conv_wgrad(int[] geom, Tensor A, Tensor G, Tensor(a!) dW, int[] tap_off, int s_ci, int s_co, '
           'Tensor(b!)? db, bool accumulate_db, Tensor? a_scale, Tensor? a_shift, int g_pitch, int g_col) -> ()')
+_d.define('conv_gemm_multi(int[] geoms, Tensor A, Tensor Wt, Tensor(a!) out, Tensor? bias, Tensor? a_scale, '
+          'Tensor? a_shift, bool stats) -> Tensor')
+_d.define('conv_wgrad_multi(int[] geoms, Tensor A, Tensor G, Tensor(a!) dW, int[] tap_off, int s_ci, int s_co, '
+          'Tensor(b!)? db, Tensor? a_scale, Tensor? a_shift, int g_pitch) -> ()')
+
+
+def _geoms_from_list(vals):
+    """1..4 geometries, one int list after the other."""
+    if len(vals) == 0 or len(vals) % _GEOM_LEN or len(vals) > 4 * _GEOM_LEN:
+        raise RuntimeError('cmvae_amd: %d entries are not 1..4 geometry lists of %d' % (len(vals), _GEOM_LEN))
+    return [geom_from_list(vals[i:i + _GEOM_LEN]) for i in range(0, len(vals), _GEOM_LEN)]
+
+
+def _conv_gemm_multi(geoms, A, Wt, out, bias, a_scale, a_shift, stats):
+    for t, n in ((A, 'A'), (Wt, 'Wt'), (out, 'out')):
+        linear._need(t, n)
+    part = conv.conv_gemm_multi(_geoms_from_list(geoms), A, Wt, out, bias=bias, a_scale=a_scale, a_shift=a_shift,
+                                stats=stats)
+    return part if part is not None else _empty(A)
+
+
+def _conv_wgrad_multi(geoms, A, G, dW, tap_off, s_ci, s_co, db, a_scale, a_shift, g_pitch):
+    for t, n in ((A, 'A'), (G, 'G'), (dW, 'dW')):
+        linear._need(t, n)
+    gs = _geoms_from_list(geoms)
+    if len(tap_off) != sum(g.ntaps for g in gs):
+        raise RuntimeError('cmvae_amd: conv_wgrad_multi takes one tap offset per tap of every geometry')
+    offs, i = [], 0
+    for g in gs:
+        offs.append(list(tap_off[i:i + g.ntaps]))
+        i += g.ntaps
+    conv.conv_wgrad_multi(gs, A, G, dW, offs, s_ci, s_co, db=db, a_scale=a_scale, a_shift=a_shift, g_pitch=g_pitch)
 
 
 def _conv_gemm(geom, A, Wt, out, bias, a_scale, a_shift, act, n_col_blocks, stats):
@@ -215,13 +247,14 @@ for _name, _fn in (('unsup_prior', _unsup_prior), ('semi_prior', _semi_prior), (
                    ('linear_fwd', _linear_fwd), ('linear_bwd', _linear_bwd), ('linear_mse_fwd', _linear_mse_fwd),
                    ('mse_act_bwd', _mse_act_bwd), ('act_bwd', _act_bwd), ('attention_fwd', _attention_fwd),
                    ('attention_bwd', _attention_bwd), ('adam_step', _adam_step), ('conv_gemm', _conv_gemm),
-                   ('conv_wgrad', _conv_wgrad)):
+                   ('conv_wgrad', _conv_wgrad), ('conv_gemm_multi', _conv_gemm_multi),
+                   ('conv_wgrad_multi', _conv_wgrad_multi)):
     _d.impl(_name, _fn, 'CUDA')
 
 REGISTERED = ('mixture_loglik_fwd', 'mixture_loglik_bwd', 'reparam_logq_fwd', 'reparam_logq_bwd', 'expm_trace',
               'unsup_prior', 'semi_prior', 'posterior_argmax', 'causal_rows', 'gram_inverse', 'center_rows',
               'linear_fwd', 'linear_bwd', 'linear_mse_fwd', 'mse_act_bwd', 'act_bwd', 'attention_fwd', 'attention_bwd',
-              'adam_step', 'conv_gemm', 'conv_wgrad')
+              'adam_step', 'conv_gemm', 'conv_wgrad', 'conv_gemm_multi', 'conv_wgrad_multi')
 
 
 # ----------------------------------------------------------------------------- whole encoder / decoder

@@ -180,6 +180,13 @@ int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks);
 int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, const float* Wt, const float* bias,
                     const float* a_scale, const float* a_shift, int act, int n_col_blocks,
                     float* out, float* stats_part, void* stream);
+/* Up to four geometries over the same operand, weight and output tensors in one launch: the sub-pixel phases of a
+ * ConvTranspose2d(64,64,k,2,1) (omniglot/module.py:50-58), each with at most 4 taps, identity activation, one
+ * 64-column block, all in the same row order.  stats_part (or NULL): [cmvae_conv_gemm_multi_grid()][128] partial
+ * column sums {sum, sum of squares} over ALL geometries' rows.                                                  */
+int cmvae_conv_gemm_multi_grid(void);
+int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, const float* A, const float* Wt, const float* bias,
+                          const float* a_scale, const float* a_shift, float* out, float* stats_part, void* stream);
 
 /* Weight gradient of the same contraction: dW[tap_off_host[t] + ci*s_ci + co*s_co] =
  * sum_r T(A[src(r,t)])[ci] * G[outpix(r), g_col + co];  db[co] (+)= sum_r G[outpix(r), g_col+co].
@@ -189,6 +196,15 @@ int cmvae_conv_wgrad(const cmvae_conv_geom* geom, const float* A, const float* a
                      const float* G, int g_pitch, int g_col, const int64_t* tap_off_host,
                      int64_t s_ci, int64_t s_co, float* dW, float* db, int accumulate_db,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* Weight and bias gradient of up to four geometries over the same tensors (the sub-pixel phases of a
+ * ConvTranspose2d, omniglot/module.py:50-58; at most 4 taps each) in one launch + one reduction.  tap_off_host: the
+ * geometries' taps one after the other; db (or NULL) receives the bias gradient over ALL geometries' rows (not
+ * accumulated).  Image counts the streaming kernel does not take (not a multiple of 16) run one launch per geometry.
+ * Workspace as for cmvae_conv_wgrad.                                                                            */
+int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, const float* A, const float* a_scale,
+                           const float* a_shift, const float* G, int g_pitch, const int64_t* tap_off_host,
+                           int64_t s_ci, int64_t s_co, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* ==== nn.Linear (+ReLU/ELU) on the gather-GEMM kernels: proj (omniglot/model.py:70-77, mimgnet/model.py:59-66),
  * the Set-Transformer projections fc_q/k/v/o and the (mu, logvar) head (omniglot/module.py:80-86, model.py:65-68),

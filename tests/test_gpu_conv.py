@@ -98,6 +98,32 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
     assert rel_err(ssum[:64], y.detach().sum((0, 2, 3))) < 1e-4
     assert rel_err(dW, w.grad) < TOL
     assert rel_err(db, b.grad) < TOL
+    # all four phases in one launch: the same rows by the same code, bit for bit; statistics over all phases
+    for fold in (True, False):
+        geoms = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=pm)[0] for py in (0, 1) for px in (0, 1)]
+        o1 = torch.full((n * Ho * Ho, 64), float('nan'), device=device)
+        for geom in geoms:
+            conv.conv_gemm(geom, xd, wprep, o1, bias=bd, a_scale=scd if fold else None, a_shift=shd if fold else None)
+        om = torch.full((n * Ho * Ho, 64), float('nan'), device=device)
+        pmulti = conv.conv_gemm_multi(geoms, xd, wprep, om, bias=bd, a_scale=scd if fold else None,
+                                      a_shift=shd if fold else None, stats=True)
+        assert torch.equal(om, o1)
+        assert pmulti.shape == (conv.gemm_multi_grid(), 128)
+        o64 = o1.double().cpu()
+        assert rel_err(pmulti.sum(0).cpu(), torch.cat([o64.sum(0), (o64 ** 2).sum(0)]).float()) < 1e-5
+    # ... and their weight gradients in one launch + one reduction
+    for fold in (True, False):
+        phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=pm) for py in (0, 1) for px in (0, 1)]
+        dWm = torch.full((64, 64, k, k), float('nan'), device=device)
+        dbm = torch.full((64,), float('nan'), device=device)
+        conv.conv_wgrad_multi([ge for ge, _ in phases], xd, gyd, dWm, [t for _, t in phases], s_ci=64 * k * k,
+                              s_co=k * k, db=dbm, a_scale=scd if fold else None, a_shift=shd if fold else None)
+        if fold:
+            assert rel_err(dWm, w.grad) < TOL
+        else:
+            ref = torch.autograd.grad(F.conv_transpose2d(x.requires_grad_(True), w, b, 2, 1), w, gy)[0]
+            assert rel_err(dWm, ref) < TOL
+        assert rel_err(dbm, b.grad) < TOL
     # data gradient wrt a (the post-activation input)
     gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=pm)
     wtd = w.detach().permute(2, 3, 0, 1).contiguous().to(device)      # [ky][kx][ci][co]
@@ -121,6 +147,26 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
         da2 = torch.empty_like(da)
         conv.conv_gemm(conv.geom_convT_dgrad(n, Hi, Hi, k)[0], gyd, wtd, da2)
         assert torch.equal(da, da2)
+
+
+def test_multi_launch_rejects_what_it_cannot_run(device):
+    """More than four taps or geometries, geometries over different tensors: an error, not a launch."""
+    from cmvae_amd import conv
+    n = 16
+    x = torch.zeros(n * 49, 64, device=device)
+    w = torch.zeros(16, 64, 64, device=device)
+    out = torch.zeros(n * 196, 64, device=device)
+    phases = [conv.geom_convT_phase(n, 7, 7, 4, py, px)[0] for py in (0, 1) for px in (0, 1)]
+    with pytest.raises(RuntimeError, match='geometries'):
+        conv.conv_gemm_multi(phases + phases[:1], x, w, out)
+    with pytest.raises(RuntimeError, match='taps'):
+        conv.conv_gemm_multi([conv.geom_conv3x3(n, 7, 7)], x, w, x.clone())
+    dW = torch.zeros(64, 64, 4, 4, device=device)
+    with pytest.raises(RuntimeError, match='taps'):
+        conv.conv_wgrad_multi([conv.geom_conv3x3(n, 7, 7)], x, x, dW, [list(range(9))], 9, 576)
+    other = conv.geom_convT_phase(n, 4, 4, 3, 0, 0)[0]
+    with pytest.raises(RuntimeError, match='same tensors'):
+        conv.conv_wgrad_multi([phases[0], other], x, out, dW, [[0, 1, 2, 3], [0, 1, 2, 3]], 1024, 16)
 
 
 @pytest.mark.parametrize('rows,K,N,act', [(300, 128, 256, 2), (1000, 256, 256, 1), (77, 256, 128, 0),

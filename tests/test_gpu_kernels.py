@@ -209,14 +209,14 @@ def test_expm_trace(device, scale):
     Ad = A.to(device).requires_grad_(True)
     h = ops.expm_trace(Ad)
     h.backward()
-    assert abs(float(h.detach()) - float(href.detach())) <= 1e-5 * max(abs(float(href)), 1e-12) + 1e-12
+    assert abs(float(h.detach()) - float(href.detach())) <= 1e-5 * max(abs(float(href.detach())), 1e-12) + 1e-12
     if scale > 0:
         assert rel_err(Ad.grad, Ar.grad) < 1e-5
     else:
         assert float(Ad.grad.abs().max()) == 0.0
     # the fp32 oracle agrees to its own rounding
     h32 = torch.trace(torch.matrix_exp(A * A)) - 64
-    assert abs(float(h.detach()) - float(h32)) <= 1e-4 * abs(float(href)) + 64 * 6e-8 * 8
+    assert abs(float(h.detach()) - float(h32)) <= 1e-4 * abs(float(href.detach())) + 64 * 6e-8 * 8
 
 
 def test_missing_gpu_tensor_raises(device):

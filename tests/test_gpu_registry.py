@@ -115,6 +115,27 @@ def test_conv_ops_take_the_geometry_as_a_list(device):
     assert torch.equal(dWw, dWg) and torch.equal(dbw, dbg)
     with pytest.raises(RuntimeError):
         O.conv_gemm(lst[:-1], x, wt, got, b, None, None, 0, 1, False)
+    # the four sub-pixel phases of a transposed conv in one launch: geometries one after the other in one list
+    k, Hi = 4, 7
+    Ho = conv.convT_out(Hi, k)
+    phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=True) for py in (0, 1) for px in (0, 1)]
+    geoms = [ge for ge, _ in phases]
+    flat = [v for ge in geoms for v in geom_to_list(ge)]
+    wt4 = (torch.randn(k * k, 64, 64, generator=g) * 0.1).to(device)
+    want = torch.empty(n * Ho * Ho, 64, device=device)
+    pw = conv.conv_gemm_multi(geoms, x, wt4, want, bias=b, stats=True)
+    got = torch.empty_like(want)
+    pg = O.conv_gemm_multi(flat, x, wt4, got, b, None, None, True)
+    assert torch.equal(got, want) and torch.equal(pg, pw)
+    gy4 = torch.randn(n * Ho * Ho, 64, generator=g).to(device)
+    dWw, dWg = torch.zeros(64, 64, k, k, device=device), torch.zeros(64, 64, k, k, device=device)
+    conv.conv_wgrad_multi(geoms, x, gy4, dWw, [t for _, t in phases], 64 * k * k, k * k, db=dbw)
+    O.conv_wgrad_multi(flat, x, gy4, dWg, [t for _, ts in phases for t in ts], 64 * k * k, k * k, dbg, None, None, 64)
+    assert torch.equal(dWw, dWg) and torch.equal(dbw, dbg)
+    with pytest.raises(RuntimeError):
+        O.conv_gemm_multi(flat[:-1], x, wt4, got, b, None, None, False)
+    with pytest.raises(RuntimeError):
+        O.conv_wgrad_multi(flat, x, gy4, dWg, [0, 1, 2], 64 * k * k, k * k, dbg, None, None, 64)
 
 
 def test_encoder_and_decoder_ops_with_autograd(device):
