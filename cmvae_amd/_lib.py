@@ -123,6 +123,9 @@ SIGNATURES = {
                                     c_void_p]),
     'cmvae_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_attention_qkv_fwd': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'cmvae_attention_qkv_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                        c_void_p, c_void_p]),
     'cmvae_adam_step_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float,
                                     c_float, c_float, c_float, c_void_p]),
     'cmvae_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float,

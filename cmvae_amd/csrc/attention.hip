@@ -1,6 +1,7 @@
 // Softmax attention core of the Set-Transformer MAB (omniglot/module.py:92-99), heads of 64 channels:
 //   O[b,i,h,:] = Q[b,i,h,:] + sum_j softmax_j(scale * Q[b,i,h,:].K[b,j,h,:]) V[b,j,h,:]
-// Q, K, V, O are [B, S, H*64] row-major (the head is a 64-column slice of the row).  One workgroup owns 16
+// Q, K, V, O are [B, S, H*64] row-major (the head is a 64-column slice of the row); Q, K, V (and dQ, dK, dV) may be
+// column slices of wider rows — the three thirds of a packed [B, S, 3*H*64] projection — with row pitch P.  One workgroup owns 16
 // query rows (forward, dQ) or 16 key rows (dK/dV) of one (episode, head); the S x 16 score strip lives in LDS.
 // Both contractions of every kernel (scores = tile . M^T into the strip, output = strip . M) run on
 // v_mfma_f32_16x16x4_f32; softmax and the dS algebra stay on the VALU, 16 lanes per row.
@@ -33,11 +34,11 @@ __device__ __forceinline__ float group16_sum(float v) {
 //  channels 16g .. 16g+15: its B operand is 64 contiguous bytes of a global row.)
 //
 // strip_mfma: T1[m][j] = tile1[m][:] . M1[j][:]  (and T2 from tile2, M2) for all j < S, 16 columns per wave step;
-// tile* are [16][64] in LDS, M* global matrices with row stride C.  emit(m, j, t1, t2) is called for every element
+// tile* are [16][64] in LDS, M* global matrices with row strides C1, C2.  emit(m, j, t1, t2) is called for every element
 // of the 16-column tiles (j may be >= S in the last tile: the caller stores zeros there).
 template <bool DUAL, typename F>
 __device__ __forceinline__ void strip_mfma(const float* tile1, const float* __restrict__ M1, const float* tile2,
-                                           const float* __restrict__ M2, int S, int C, F&& emit) {
+                                           const float* __restrict__ M2, int S, int C1, int C2, F&& emit) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     float a1[16], a2[DUAL ? 16 : 1];
@@ -56,8 +57,8 @@ __device__ __forceinline__ void strip_mfma(const float* tile1, const float* __re
         float4 b1[4], b2[DUAL ? 4 : 1];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            b1[c] = *reinterpret_cast<const float4*>(M1 + (long)jc * C + 16 * g + 4 * c);
-            if (DUAL) b2[c] = *reinterpret_cast<const float4*>(M2 + (long)jc * C + 16 * g + 4 * c);
+            b1[c] = *reinterpret_cast<const float4*>(M1 + (long)jc * C1 + 16 * g + 4 * c);
+            if (DUAL) b2[c] = *reinterpret_cast<const float4*>(M2 + (long)jc * C2 + 16 * g + 4 * c);
         }
         floatx4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, r0 = p0, r1 = p0;     // two chains per product
 #pragma unroll
@@ -85,7 +86,8 @@ __device__ __forceinline__ void strip_mfma(const float* tile1, const float* __re
 // element reg <-> (row 4*(lane>>4) + reg, channel 16w + (lane&15)).
 template <bool DUAL>
 __device__ __forceinline__ void out_mfma(const float* strip1, const float* __restrict__ M1, const float* strip2,
-                                         const float* __restrict__ M2, int S, int C, floatx4& o1, floatx4& o2) {
+                                         const float* __restrict__ M2, int S, int C1, int C2, floatx4& o1,
+                                         floatx4& o2) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int SPP = strip_pitch(S), ntile = (S + 15) / 16;
@@ -99,10 +101,10 @@ __device__ __forceinline__ void out_mfma(const float* strip1, const float* __res
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                     // four k-steps of four rows: all operands requested first
             const int j = 16 * jt + 4 * q + g;
-            const long o = (long)(j < S ? j : S - 1) * C;
+            const long jr = j < S ? j : S - 1;
             a1[q] = s1[16 * jt + 4 * q];
-            b1[q] = m1[o];
-            if (DUAL) { a2[q] = s2[16 * jt + 4 * q]; b2[q] = m2[o]; }
+            b1[q] = m1[jr * C1];
+            if (DUAL) { a2[q] = s2[16 * jt + 4 * q]; b2[q] = m2[jr * C2]; }
         }
         p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b1[0], p0, 0, 0, 0);
         p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b1[1], p1, 0, 0, 0);
@@ -123,21 +125,22 @@ __device__ __forceinline__ void out_mfma(const float* strip1, const float* __res
 
 // ---------------------------------------------------------------------------- forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                       const float* __restrict__ V, int S, int C, float scale,
-                                                       float* __restrict__ O, float* __restrict__ lse) {
+                                                       const float* __restrict__ V, int S, int C, int P,
+                                                       float scale, float* __restrict__ O,
+                                                       float* __restrict__ lse) {
     extern __shared__ __align__(16) float smem[];
     float* qs = smem;                    // [16][64] scaled queries
     float* sc = smem + AT * 64;          // [16][SPP] scores, then probabilities
     const int SPP = strip_pitch(S);
     const int t = threadIdx.x, r = t >> 4, c4 = t & 15;
     const int s0 = blockIdx.x * AT, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
-    const long base = (long)b * S * C + h * 64;
+    const long base = (long)b * S * C + h * 64, pbase = (long)b * S * P + h * 64;
     const bool rv = s0 + r < S;
     float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rv) qv = *reinterpret_cast<const float4*>(Q + base + (long)(s0 + r) * C + 4 * c4);
+    if (rv) qv = *reinterpret_cast<const float4*>(Q + pbase + (long)(s0 + r) * P + 4 * c4);
     *reinterpret_cast<float4*>(qs + r * 64 + 4 * c4) = make_float4(qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale);
     __syncthreads();
-    strip_mfma<false>(qs, K + base, nullptr, nullptr, S, C,
+    strip_mfma<false>(qs, K + pbase, nullptr, nullptr, S, P, P,
                       [&](int m, int j, float v, float) { sc[m * SPP + j] = j < S ? v : 0.f; });
     __syncthreads();
     {   // softmax of row r by its 16 lanes
@@ -157,14 +160,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
     __syncthreads();
     floatx4 acc, unused;
-    out_mfma<false>(sc, V + base, nullptr, nullptr, S, C, acc, unused);
+    out_mfma<false>(sc, V + pbase, nullptr, nullptr, S, P, P, acc, unused);
     const int lane = t & 63, w = t >> 6, n = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int row = s0 + 4 * g + reg;
         if (row < S) {
-            const long o = base + (long)row * C + 16 * w + n;
-            O[o] = Q[o] + acc[reg];
+            O[base + (long)row * C + 16 * w + n] = Q[pbase + (long)row * P + 16 * w + n] + acc[reg];
         }
     }
 }
@@ -174,8 +176,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                           const float* __restrict__ V,
                                                           const float* __restrict__ lse,
-                                                          const float* __restrict__ dO, int S, int C, float scale,
-                                                          float* __restrict__ dQ, float* __restrict__ delta) {
+                                                          const float* __restrict__ dO, int S, int C, int P,
+                                                          float scale, float* __restrict__ dQ,
+                                                          float* __restrict__ delta) {
     extern __shared__ __align__(16) float smem[];
     float* qs = smem;                    // [16][64] scaled queries
     float* ds = smem + AT * 64;          // [16][64] dO rows
@@ -184,11 +187,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     float* sd = sp + AT * SPP;           // [16][SPP] dP
     const int t = threadIdx.x, r = t >> 4, c4 = t & 15;
     const int s0 = blockIdx.x * AT, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
-    const long base = (long)b * S * C + h * 64;
+    const long base = (long)b * S * C + h * 64, pbase = (long)b * S * P + h * 64;
     const bool rv = s0 + r < S;
     float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
     if (rv) {
-        qv = *reinterpret_cast<const float4*>(Q + base + (long)(s0 + r) * C + 4 * c4);
+        qv = *reinterpret_cast<const float4*>(Q + pbase + (long)(s0 + r) * P + 4 * c4);
         gv = *reinterpret_cast<const float4*>(dO + base + (long)(s0 + r) * C + 4 * c4);
     }
     *reinterpret_cast<float4*>(qs + r * 64 + 4 * c4) = make_float4(qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale);
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     __shared__ float row_lse[AT];
     if (t < AT) row_lse[t] = s0 + t < S ? lse[((long)b * H + h) * S + s0 + t] : 0.f;
     __syncthreads();
-    strip_mfma<true>(qs, K + base, ds, V + base, S, C, [&](int m, int j, float v1, float v2) {
+    strip_mfma<true>(qs, K + pbase, ds, V + pbase, S, P, P, [&](int m, int j, float v1, float v2) {
         const bool in = j < S;
         sp[m * SPP + j] = in ? expf(v1 - row_lse[m]) : 0.f;
         sd[m * SPP + j] = in ? v2 : 0.f;
@@ -211,14 +214,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     }
     __syncthreads();
     floatx4 acc, unused;
-    out_mfma<false>(sp, K + base, nullptr, nullptr, S, C, acc, unused);
+    out_mfma<false>(sp, K + pbase, nullptr, nullptr, S, P, P, acc, unused);
     const int lane = t & 63, w = t >> 6, n = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int row = s0 + 4 * g + reg;
         if (row < S) {
-            const long o = base + (long)row * C + 16 * w + n;
-            dQ[o] = fmaf(scale, acc[reg], dO[o]);
+            dQ[pbase + (long)row * P + 16 * w + n] = fmaf(scale, acc[reg], dO[base + (long)row * C + 16 * w + n]);
         }
     }
 }
@@ -229,8 +231,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                                                            const float* __restrict__ V,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
-                                                           const float* __restrict__ dO, int S, int C, float scale,
-                                                           float* __restrict__ dK, float* __restrict__ dV) {
+                                                           const float* __restrict__ dO, int S, int C, int P,
+                                                           float scale, float* __restrict__ dK,
+                                                           float* __restrict__ dV) {
     extern __shared__ __align__(16) float smem[];
     float* ks = smem;                    // [16][64] keys, pre-scaled
     float* vs = smem + AT * 64;          // [16][64] values
@@ -239,19 +242,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     float* st = pt + AT * SPP;           // [16][SPP] dS^T
     const int t = threadIdx.x, r = t >> 4, c4 = t & 15;
     const int j0 = blockIdx.x * AT, h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
-    const long base = (long)b * S * C + h * 64;
+    const long base = (long)b * S * C + h * 64, pbase = (long)b * S * P + h * 64;
     const bool rv = j0 + r < S;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
     if (rv) {
-        kv = *reinterpret_cast<const float4*>(K + base + (long)(j0 + r) * C + 4 * c4);
-        vv = *reinterpret_cast<const float4*>(V + base + (long)(j0 + r) * C + 4 * c4);
+        kv = *reinterpret_cast<const float4*>(K + pbase + (long)(j0 + r) * P + 4 * c4);
+        vv = *reinterpret_cast<const float4*>(V + pbase + (long)(j0 + r) * P + 4 * c4);
     }
     *reinterpret_cast<float4*>(ks + r * 64 + 4 * c4) = make_float4(kv.x * scale, kv.y * scale, kv.z * scale, kv.w * scale);
     *reinterpret_cast<float4*>(vs + r * 64 + 4 * c4) = vv;
     __syncthreads();
     const long sbase = ((long)b * H + h) * S;
     // transposed strips: row = key of this workgroup, column = query i
-    strip_mfma<true>(ks, Q + base, vs, dO + base, S, C, [&](int m, int i, float v1, float v2) {
+    strip_mfma<true>(ks, Q + pbase, vs, dO + base, S, P, C, [&](int m, int i, float v1, float v2) {
         const bool in = i < S;
         const int ic = in ? i : S - 1;
         const float p = in ? expf(v1 - lse[sbase + ic]) : 0.f;
@@ -260,13 +263,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     });
     __syncthreads();
     floatx4 av, ak;
-    out_mfma<true>(pt, dO + base, st, Q + base, S, C, av, ak);
+    out_mfma<true>(pt, dO + base, st, Q + pbase, S, C, P, av, ak);
     const int lane = t & 63, w = t >> 6, n = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int row = j0 + 4 * g + reg;
         if (row < S) {
-            const long o = base + (long)row * C + 16 * w + n;
+            const long o = pbase + (long)row * P + 16 * w + n;
             dV[o] = av[reg];
             dK[o] = scale * ak[reg];
         }
@@ -295,16 +298,35 @@ static void allow_large_lds() {
 
 using namespace cmvae;
 
+static int attention_fwd(const float* Q, const float* K, const float* V, int pitch, int B, int S, int heads, float scale,
+                         float* O, float* lse, void* stream) {
+    const size_t lds = (size_t)(AT * 64 + AT * strip_pitch(S)) * sizeof(float);
+    allow_large_lds();
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + AT - 1) / AT, heads, B), dim3(256), lds, (hipStream_t)stream, Q, K, V,
+                       S, heads * 64, pitch, scale, O, lse);
+    return check_launch("attn_fwd_kernel");
+}
+
+static int attention_bwd(const float* Q, const float* K, const float* V, int pitch, const float* lse, const float* dO,
+                         int B, int S, int heads, float scale, float* dQ, float* dK, float* dV, float* delta,
+                         void* stream) {
+    const size_t lds = (size_t)(2 * AT * 64 + 2 * AT * strip_pitch(S)) * sizeof(float);
+    allow_large_lds();
+    const dim3 grid((S + AT - 1) / AT, heads, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds, (hipStream_t)stream, Q, K, V, lse, dO, S,
+                       heads * 64, pitch, scale, dQ, delta);
+    if (int e = check_launch("attn_bwd_dq_kernel")) return e;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), lds, (hipStream_t)stream, Q, K, V, lse, delta, dO, S,
+                       heads * 64, pitch, scale, dK, dV);
+    return check_launch("attn_bwd_dkv_kernel");
+}
+
 extern "C" int cmvae_attention_fwd(const float* Q, const float* K, const float* V, int B, int S, int heads,
                                    float scale, float* O, float* lse, void* stream) {
     cmvae::clear_stale_error();
     CMVAE_REQUIRE(Q && K && V && O && lse, "cmvae_attention_fwd: NULL argument");
     if (int e = check_attn("cmvae_attention_fwd", B, S, heads)) return e;
-    const size_t lds = (size_t)(AT * 64 + AT * strip_pitch(S)) * sizeof(float);
-    allow_large_lds();
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + AT - 1) / AT, heads, B), dim3(256), lds, (hipStream_t)stream, Q, K, V,
-                       S, heads * 64, scale, O, lse);
-    return check_launch("attn_fwd_kernel");
+    return attention_fwd(Q, K, V, heads * 64, B, S, heads, scale, O, lse, stream);
 }
 
 extern "C" int cmvae_attention_bwd(const float* Q, const float* K, const float* V, const float* lse, const float* dO,
@@ -313,13 +335,26 @@ extern "C" int cmvae_attention_bwd(const float* Q, const float* K, const float* 
     cmvae::clear_stale_error();
     CMVAE_REQUIRE(Q && K && V && lse && dO && dQ && dK && dV && delta, "cmvae_attention_bwd: NULL argument");
     if (int e = check_attn("cmvae_attention_bwd", B, S, heads)) return e;
-    const size_t lds = (size_t)(2 * AT * 64 + 2 * AT * strip_pitch(S)) * sizeof(float);
-    allow_large_lds();
-    const dim3 grid((S + AT - 1) / AT, heads, B);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds, (hipStream_t)stream, Q, K, V, lse, dO, S,
-                       heads * 64, scale, dQ, delta);
-    if (int e = check_launch("attn_bwd_dq_kernel")) return e;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), lds, (hipStream_t)stream, Q, K, V, lse, delta, dO, S,
-                       heads * 64, scale, dK, dV);
-    return check_launch("attn_bwd_dkv_kernel");
+    return attention_bwd(Q, K, V, heads * 64, lse, dO, B, S, heads, scale, dQ, dK, dV, delta, stream);
+}
+
+// The same over a packed projection QKV [B, S, 3*heads*64] = [q | k | v] per row (one GEMM instead of three for the
+// self-attention blocks, where fc_q, fc_k and fc_v read the same rows); dQKV has the same layout.
+extern "C" int cmvae_attention_qkv_fwd(const float* QKV, int B, int S, int heads, float scale, float* O, float* lse,
+                                       void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(QKV && O && lse, "cmvae_attention_qkv_fwd: NULL argument");
+    if (int e = check_attn("cmvae_attention_qkv_fwd", B, S, heads)) return e;
+    const int C = heads * 64;
+    return attention_fwd(QKV, QKV + C, QKV + 2 * C, 3 * C, B, S, heads, scale, O, lse, stream);
+}
+
+extern "C" int cmvae_attention_qkv_bwd(const float* QKV, const float* lse, const float* dO, int B, int S, int heads,
+                                       float scale, float* dQKV, float* delta, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(QKV && lse && dO && dQKV && delta, "cmvae_attention_qkv_bwd: NULL argument");
+    if (int e = check_attn("cmvae_attention_qkv_bwd", B, S, heads)) return e;
+    const int C = heads * 64;
+    return attention_bwd(QKV, QKV + C, QKV + 2 * C, 3 * C, lse, dO, B, S, heads, scale, dQKV, dQKV + C, dQKV + 2 * C,
+                         delta, stream);
 }

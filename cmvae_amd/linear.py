@@ -224,6 +224,54 @@ def attention(q, k, v, heads, scale):
     return _Attention.apply(q, k, v, heads, float(scale))
 
 
+class _SelfAttention(torch.autograd.Function):
+    """fc_q, fc_k, fc_v of a self-attention block as one GEMM over the stacked weights, and the attention core on the
+    packed projection (cmvae_attention_qkv_*)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, heads, scale):
+        _need(x, 'x'); _need(wq, 'fc_q.weight')
+        B, S, Cin = x.shape
+        C = 64 * heads
+        for w_ in (wq, wk, wv):
+            if tuple(w_.shape) != (C, Cin):
+                raise RuntimeError('cmvae_amd self_attention: projection weights must be [%d, %d], got %s'
+                                   % (C, Cin, tuple(w_.shape)))
+        x2 = x.reshape(-1, Cin)
+        if x2.stride(1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        w = torch.cat([wq, wk, wv])
+        b = torch.cat([bq, bk, bv])
+        qkv = linear_fwd(x2, w, b, 0)                                     # [B*S, 3C] = [q | k | v]
+        o = torch.empty(B, S, C, device=x.device, dtype=torch.float32)
+        lse = torch.empty(B, heads, S, device=x.device, dtype=torch.float32)
+        check(lib.cmvae_attention_qkv_fwd(_p(qkv), B, S, heads, scale, _p(o), _p(lse), _stream()),
+              'cmvae_attention_qkv_fwd')
+        ctx.heads, ctx.scale, ctx.shape = heads, scale, x.shape
+        ctx.save_for_backward(x2, w, qkv, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        x2, w, qkv, lse = ctx.saved_tensors
+        B, S, _ = ctx.shape
+        C = 64 * ctx.heads
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        check(lib.cmvae_attention_qkv_bwd(_p(qkv), _p(lse), _p(do), B, S, ctx.heads, ctx.scale, _p(dqkv), _p(delta),
+                                          _stream()), 'cmvae_attention_qkv_bwd')
+        dx, dW, db = linear_bwd(x2, w, dqkv, ctx.needs_input_grad[0], True)
+        return ((None if dx is None else dx.view(ctx.shape)), dW[:C], db[:C], dW[C:2 * C], db[C:2 * C], dW[2 * C:],
+                db[2 * C:], None, None)
+
+
+def self_attention(x, wq, bq, wk, bk, wv, bv, heads, scale):
+    """attention(fc_q(x), fc_k(x), fc_v(x)) for x [B, S, C_in] (SAB = MAB(X, X), omniglot/module.py:102-108): the same
+    values as the three `linear` calls + `attention`, from one projection GEMM."""
+    return _SelfAttention.apply(x, wq, bq, wk, bk, wv, bv, heads, float(scale))
+
+
 class FlatAdam:
     """torch.optim.Adam(params, lr, betas, eps, weight_decay) over the parameters of a `dist.FlatGrads`.
 

@@ -11,12 +11,17 @@ Unlike the reference nothing here calls ``.cuda()``: modules are built on the CP
 with ``.to(device)``.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from . import dist as _dist
-from .linear import linear as _linear, causal_mlp as _causal_mlp, attention as _attention
+from .linear import linear as _linear, causal_mlp as _causal_mlp, attention as _attention, \
+    self_attention as _self_attention
+
+# CMVAE_FUSED_QKV=0: fc_q, fc_k, fc_v of the self-attention blocks as three GEMMs (A/B measurements)
+FUSED_QKV = os.environ.get('CMVAE_FUSED_QKV', '1') not in ('', '0')
 
 
 class EpisodeBatchNorm2d(nn.BatchNorm2d):
@@ -90,6 +95,11 @@ class MAB(nn.Module):
         self.fc_o = nn.Linear(dim_V, dim_V)
 
     def forward(self, Q, K):
+        if Q is K and Q.dim() == 3 and Q.shape[0] * Q.shape[1] > 0 and FUSED_QKV:
+            # self-attention: the three projections read the same rows -> one GEMM over the stacked weights
+            o = _self_attention(Q, self.fc_q.weight, self.fc_q.bias, self.fc_k.weight, self.fc_k.bias,
+                                self.fc_v.weight, self.fc_v.bias, self.num_heads, 1.0 / math.sqrt(self.dim_V))
+            return o + _linear(o, self.fc_o.weight, self.fc_o.bias, 'relu')
         q = _linear(Q, self.fc_q.weight, self.fc_q.bias)
         k = _linear(K, self.fc_k.weight, self.fc_k.bias)
         v = _linear(K, self.fc_v.weight, self.fc_v.bias)

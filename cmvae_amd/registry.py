@@ -105,6 +105,8 @@ _d.define('act_bwd(Tensor dy, Tensor y, int act) -> Tensor')
 _d.define('attention_fwd(Tensor q, Tensor k, Tensor v, int heads, float scale) -> (Tensor, Tensor)')
 _d.define('attention_bwd(Tensor q, Tensor k, Tensor v, Tensor lse, Tensor do, int heads, float scale)'
           ' -> (Tensor, Tensor, Tensor)')
+_d.define('attention_qkv_fwd(Tensor qkv, int heads, float scale) -> (Tensor, Tensor)')
+_d.define('attention_qkv_bwd(Tensor qkv, Tensor lse, Tensor do, int heads, float scale) -> Tensor')
 _d.define('adam_step(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, int step, float lr, '
           'float beta1, float beta2, float eps, float weight_decay) -> ()')
 
@@ -179,6 +181,37 @@ def _attention_bwd(q, k, v, lse, do, heads, scale):
     return dq, dk, dv
 
 
+def _qkv3(qkv, heads):
+    linear._need(qkv, 'qkv')
+    if qkv.dim() != 3 or qkv.shape[2] != 192 * heads:
+        raise RuntimeError('cmvae_amd attention: the packed projection is [B, S, 3 * 64 * heads], got %s for %d heads'
+                           % (tuple(qkv.shape), heads))
+    return qkv.contiguous()
+
+
+def _attention_qkv_fwd(qkv, heads, scale):
+    qkv = _qkv3(qkv, heads)
+    B, S, _ = qkv.shape
+    o = torch.empty(B, S, 64 * heads, device=qkv.device, dtype=torch.float32)
+    lse = torch.empty(B, heads, S, device=qkv.device, dtype=torch.float32)
+    check(lib.cmvae_attention_qkv_fwd(_p(qkv), B, S, heads, scale, _p(o), _p(lse), ops._stream()),
+          'cmvae_attention_qkv_fwd')
+    return o, lse
+
+
+def _attention_qkv_bwd(qkv, lse, do, heads, scale):
+    qkv = _qkv3(qkv, heads)
+    B, S, _ = qkv.shape
+    do, lse = do.contiguous(), lse.contiguous()
+    if tuple(do.shape) != (B, S, 64 * heads) or tuple(lse.shape) != (B, heads, S):
+        raise RuntimeError('cmvae_amd attention: do / lse do not match the packed projection')
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    check(lib.cmvae_attention_qkv_bwd(_p(qkv), _p(lse), _p(do), B, S, heads, scale, _p(dqkv), _p(delta),
+                                      ops._stream()), 'cmvae_attention_qkv_bwd')
+    return dqkv
+
+
 def _adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay):
     for t, n in ((param, 'param'), (grad, 'grad'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
         ops._req(t, n)
@@ -247,6 +280,7 @@ for _name, _fn in (('unsup_prior', _unsup_prior), ('semi_prior', _semi_prior), (
                    ('linear_fwd', _linear_fwd), ('linear_bwd', _linear_bwd), ('linear_mse_fwd', _linear_mse_fwd),
                    ('mse_act_bwd', _mse_act_bwd), ('act_bwd', _act_bwd), ('attention_fwd', _attention_fwd),
                    ('attention_bwd', _attention_bwd), ('adam_step', _adam_step), ('conv_gemm', _conv_gemm),
+                   ('attention_qkv_fwd', _attention_qkv_fwd), ('attention_qkv_bwd', _attention_qkv_bwd),
                    ('conv_wgrad', _conv_wgrad), ('conv_gemm_multi', _conv_gemm_multi),
                    ('conv_wgrad_multi', _conv_wgrad_multi)):
     _d.impl(_name, _fn, 'CUDA')
@@ -254,7 +288,8 @@ for _name, _fn in (('unsup_prior', _unsup_prior), ('semi_prior', _semi_prior), (
 REGISTERED = ('mixture_loglik_fwd', 'mixture_loglik_bwd', 'reparam_logq_fwd', 'reparam_logq_bwd', 'expm_trace',
               'unsup_prior', 'semi_prior', 'posterior_argmax', 'causal_rows', 'gram_inverse', 'center_rows',
               'linear_fwd', 'linear_bwd', 'linear_mse_fwd', 'mse_act_bwd', 'act_bwd', 'attention_fwd', 'attention_bwd',
-              'adam_step', 'conv_gemm', 'conv_wgrad', 'conv_gemm_multi', 'conv_wgrad_multi')
+              'adam_step', 'conv_gemm', 'conv_wgrad', 'conv_gemm_multi', 'conv_wgrad_multi', 'attention_qkv_fwd',
+              'attention_qkv_bwd')
 
 
 # ----------------------------------------------------------------------------- whole encoder / decoder

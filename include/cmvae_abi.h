@@ -240,6 +240,13 @@ int cmvae_attention_fwd(const float* Q, const float* K, const float* V, int B, i
 int cmvae_attention_bwd(const float* Q, const float* K, const float* V, const float* lse, const float* dO,
                         int B, int S, int heads, float scale, float* dQ, float* dK, float* dV, float* delta,
                         void* stream);
+/* The same over a packed projection QKV [B, S, 3*heads*64], row = [q | k | v] — the self-attention blocks (SAB,
+ * omniglot/module.py:102-108: MAB(X, X)), whose fc_q, fc_k, fc_v read the same rows and so run as ONE GEMM with the
+ * three weights stacked.  dQKV has the layout of QKV and feeds that GEMM's backward.                          */
+int cmvae_attention_qkv_fwd(const float* QKV, int B, int S, int heads, float scale, float* O, float* lse,
+                            void* stream);
+int cmvae_attention_qkv_bwd(const float* QKV, const float* lse, const float* dO, int B, int S, int heads,
+                            float scale, float* dQKV, float* delta, void* stream);
 
 /* ==== NOTEARS-MLP causal layer on bulk rows (CausalEncoder.forward on [B*N,64], omniglot/module.py:165-188,
  * LocallyConnected :232-288).  hid [rows,2048] = elu(fc1(x)) comes from cmvae_linear_fwd(act=2);

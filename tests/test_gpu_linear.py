@@ -164,6 +164,46 @@ def test_attention_core(B, S, heads):
         assert _rel(a.grad, b.grad) < 2e-5
 
 
+@pytest.mark.parametrize('B,S,heads,Cin', [(4, 300, 4, 256), (3, 37, 4, 256), (2, 1, 4, 256), (2, 100, 1, 128),
+                                             (16, 5, 4, 256)])
+def test_self_attention_one_projection_gemm(B, S, heads, Cin):
+    """SAB = MAB(X, X) (omniglot/module.py:102-108): fc_q, fc_k, fc_v as one GEMM over the stacked weights and the
+    attention core on the packed projection give the three-GEMM path's output bit for bit (same per-column sums) and
+    its gradients to rounding (dx is one K = 3C contraction instead of three added up); both against float64."""
+    from cmvae_amd.linear import attention, linear, self_attention
+    g = torch.Generator().manual_seed(S + Cin)
+    C = 64 * heads
+    x = torch.randn(B, S, Cin, generator=g)
+    ws = [torch.randn(C, Cin, generator=g) / np.sqrt(Cin) for _ in range(3)]
+    bs = [torch.randn(C, generator=g) * 0.1 for _ in range(3)]
+    go = torch.randn(B, S, C, generator=g)
+    scale = 1.0 / np.sqrt(C)
+
+    def leaves():
+        return [t.cuda().requires_grad_(True) for t in [x] + ws + bs]
+
+    a = leaves()
+    o1 = attention(linear(a[0], a[1], a[4]), linear(a[0], a[2], a[5]), linear(a[0], a[3], a[6]), heads, scale)
+    o1.backward(go.cuda())
+    f = leaves()
+    o2 = self_attention(f[0], f[1], f[4], f[2], f[5], f[3], f[6], heads, scale)
+    o2.backward(go.cuda())
+    assert torch.equal(o1, o2)
+    r = [t.double().requires_grad_(True) for t in [x] + ws + bs]
+    qh, kh, vh = ((r[0].matmul(r[1 + i].t()) + r[4 + i]).view(B, S, heads, 64).transpose(1, 2) for i in range(3))
+    orf = (qh + torch.softmax(qh.matmul(kh.transpose(-1, -2)) * scale, -1).matmul(vh)).transpose(1, 2).reshape(B, S, C)
+    orf.backward(go.double())
+    assert _rel(o2, orf) < 1e-5
+    for i, (t1, t2, tr) in enumerate(zip(a, f, r)):
+        if i == 5:        # fc_k's bias shifts every score of a row alike: its gradient is zero up to rounding
+            assert float(t2.grad.abs().max()) < 1e-5 and float(t1.grad.abs().max()) < 1e-5
+            continue
+        assert _rel(t2.grad, tr.grad) < 3e-5
+        assert _rel(t2.grad, t1.grad) < 1e-5
+    with pytest.raises(RuntimeError):
+        self_attention(f[0], f[1][:, :64], f[4], f[2], f[5], f[3], f[6], heads, scale)
+
+
 def test_attention_rejects_bad_shapes():
     from cmvae_amd.linear import attention
     with pytest.raises(RuntimeError):

@@ -81,7 +81,7 @@ def _mask_flips(taps_g, taps_o):
 def _check_forward(model, oracle, out_o, ex_o, out_g, ex_g):
     names = ['rec_loss', 'kl_loss', 'h_augment']
     for i, n in enumerate(names, start=1):
-        a, b = float(out_g[i]), float(out_o[i])
+        a, b = float(out_g[i].detach()), float(out_o[i].detach())
         assert abs(a - b) <= RTOL * abs(b) + 1e-7, '%s: gpu %r oracle %r' % (n, a, b)
     # bare h suffers the oracle's own `trace - 64` cancellation: compare at the fp32-ulp(64) floor
     hg, ho = float(out_g[4].detach()), float(out_o[4].detach())

@@ -78,6 +78,14 @@ def test_linear_attention_adam_ops(device):
     qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
     attention(qr, kr, vr, 2, 0.125).backward(do)
     assert torch.equal(dq, qr.grad) and torch.equal(dk, kr.grad) and torch.equal(dv, vr.grad)
+    # the packed projection [q | k | v] per row: the same values from column slices
+    qkv = torch.cat([q, k, v], 2)
+    o2, lse2 = O.attention_qkv_fwd(qkv, 2, 0.125)
+    assert torch.equal(o2, o) and torch.equal(lse2, lse)
+    dqkv = O.attention_qkv_bwd(qkv, lse2, do, 2, 0.125)
+    assert torch.equal(dqkv, torch.cat([dq, dk, dv], 2))
+    with pytest.raises(RuntimeError):
+        O.attention_qkv_fwd(qkv[:, :, :-64], 2, 0.125)
     n = 1024
     p0 = torch.randn(n, generator=g)
     gr = torch.randn(n, generator=g)
