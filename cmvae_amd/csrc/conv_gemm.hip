@@ -1251,8 +1251,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, i
 // workgroups begin[k] .. begin[k+1]-1 stream phase k's rows.  Every workgroup leaves 4 tap blocks of partials (a
 // phase with fewer taps leaves the rest unwritten and unread) and one bias-gradient partial: every phase covers
 // output pixels of its own, so the bias gradient is the sum over all of them.
+// Workgroups from db_blocks on leave no bias-gradient partial (tap groups of ONE geometry share their gradient rows).
 template <bool HAS_T>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_stream_multi_kernel(ConvGeomMulti p, int nimg,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_stream_multi_kernel(ConvGeomMulti p, int nimg, int db_blocks,
                                                                          const float* __restrict__ A,
                                                                          const float* __restrict__ a_scale,
                                                                          const float* __restrict__ a_shift,
@@ -1265,7 +1266,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_multi_kernel(ConvGeo
     const ConvGeom& g = p.g[ph];
     const int b0 = p.begin[ph];
     wgrad_stream_body<HAS_T>(g, 0, g.ntaps, nimg, A, a_scale, a_shift, G, g_pitch, 0, part + (long)b0 * 4 * 4096,
-                             db_part ? db_part + (long)b0 * 64 : nullptr, b - b0, p.begin[ph + 1] - b0, 4, comb);
+                             (db_part && b < db_blocks) ? db_part + (long)b0 * 64 : nullptr, b - b0,
+                             p.begin[ph + 1] - b0, 4, comb);
 }
 
 // out[y*y_stride + tap_off[NT*z + t] + ci*s_ci + co*s_co] = sum_blk part[(z,y)][blk][t][ci][co];
@@ -1331,7 +1333,8 @@ struct WgradMultiOut {
 __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const float* __restrict__ part, WgradMultiOut o,
                                                                   float* __restrict__ dW,
                                                                   const float* __restrict__ db_part,
-                                                                  float* __restrict__ db, int nblk_all) {
+                                                                  float* __restrict__ db, int nblk_all,
+                                                                  int accumulate_db) {
     __shared__ float red[16 * 64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + c, ph = blockIdx.y;
@@ -1367,7 +1370,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const float* _
         const int t = e >> 12, ci = (e >> 6) & 63, co = e & 63;
         dW[o.tap_off[4 * ph + t] + ci * o.s_ci + co * o.s_co] = s;
     } else {
-        db[c] = s;
+        db[c] = accumulate_db ? db[c] + s : s;
     }
 }
 
@@ -1571,6 +1574,48 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
     float* part = (float*)workspace;
     float* db_part = (float*)((char*)workspace + align_up((size_t)max_blocks * 4 * 4096 * sizeof(float)));
     if ((long)nblk * ny * nz_all > max_blocks) return set_error("wgrad: %d x %d column/tap blocks exceed the workspace", ny, nz_all);
+    {   // 5 .. 16 taps of one gradient column block (the 3x3 convs: 4 + 4 + 1): the tap groups side by side in one
+        // launch and one reduction, workgroups in proportion to each group's tap work
+        const int npix = g.Hg * g.Wg, nimg = g.rows_total / npix;
+        if (wgrad_stream_enabled() && ny == 1 && g_col == 0 && g.ntaps > 4 && g.ntaps <= 16 && g.ntaps % 4 != 0 &&
+            g.rows_total % npix == 0 && nimg % 16 == 0 && (long)nimg * g.Ho * g.Wo * g_pitch < (1L << 31)) {
+            ConvGeomMulti p{};
+            WgradMultiOut mo{};
+            mo.s_ci = s_ci; mo.s_co = s_co;
+            const int ngrp = (g.ntaps + 3) / 4;
+            const long chunks = (long)(nimg / 16) * npix;
+            double wk[4] = {0., 0., 0., 0.}, wsum = 0.;
+            for (int k = 0; k < ngrp; ++k) {
+                const int t0 = 4 * k, nt = g.ntaps - t0 < 4 ? g.ntaps - t0 : 4;
+                p.g[k] = g;
+                p.g[k].ntaps = nt;
+                for (int t = 0; t < nt; ++t) {
+                    p.g[k].dy[t] = g.dy[t0 + t]; p.g[k].dx[t] = g.dx[t0 + t];
+                    p.g[k].a_col[t] = g.a_col[t0 + t]; p.g[k].w_off[t] = g.w_off[t0 + t];
+                    mo.tap_off[4 * k + t] = tap_off_host[t0 + t];
+                }
+                mo.ntaps[k] = nt;
+                wk[k] = (double)chunks / (nt > 2 ? 2 : 4) * (nt == 1 ? 0.6 : 1.0);
+                wsum += wk[k];
+            }
+            int used = 0;
+            for (int k = 0; k <= 4; ++k) {
+                p.begin[k] = mo.begin[k] = used;
+                if (k >= ngrp) { if (k < 4) p.g[k] = p.g[0]; continue; }
+                long n = (long)(max_blocks * wk[k] / wsum);
+                if (n > chunks) n = chunks;
+                if (n < 1) n = 1;
+                used += (int)n;
+            }
+            float* dbp = db ? db_part : nullptr;
+            const int db_blocks = p.begin[1];          // every group reads the same gradient rows: group 0 sums them
+            if (a_scale) hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<true>, dim3(used), dim3(256), 0, st, p, nimg, db_blocks, A, a_scale, a_shift, G, g_pitch, part, dbp);
+            else hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<false>, dim3(used), dim3(256), 0, st, p, nimg, db_blocks, A, a_scale, a_shift, G, g_pitch, part, dbp);
+            if (int e = check_launch("conv_wgrad_stream_multi_kernel")) return e;
+            hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(4 * 64 + 1, ngrp), dim3(1024), 0, st, part, mo, dW, dbp, db, db_blocks, accumulate_db);
+            return check_launch("wgrad_reduce_multi_kernel");
+        }
+    }
     WgradOut o{};
     o.s_ci = s_ci; o.s_co = s_co; o.y_stride = y_stride;
     for (int t0 = 0; t0 < g.ntaps; t0 += nt_launch * nz_all) {
@@ -1691,10 +1736,10 @@ extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, c
     float* part = (float*)workspace;
     float* db_part = (float*)((char*)workspace + align_up((size_t)max_blocks * 4 * 4096 * sizeof(float)));
     float* dbp = db ? db_part : nullptr;
-    if (a_scale) hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<true>, dim3(used), dim3(256), 0, st, p, nimg, A, a_scale, a_shift, G, g_pitch, part, dbp);
-    else hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<false>, dim3(used), dim3(256), 0, st, p, nimg, A, a_scale, a_shift, G, g_pitch, part, dbp);
+    if (a_scale) hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<true>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
+    else hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<false>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
     if (int e = check_launch("conv_wgrad_stream_multi_kernel")) return e;
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(4 * 64 + 1, ngeom), dim3(1024), 0, st, part, o, dW, dbp, db, used);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(4 * 64 + 1, ngeom), dim3(1024), 0, st, part, o, dW, dbp, db, used, 0);
     return check_launch("wgrad_reduce_multi_kernel");
 }
 
