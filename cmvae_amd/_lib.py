@@ -94,6 +94,7 @@ SIGNATURES = {
     'cmvae_conv_gemm_grid': (c_int, [c_int, c_int]),
     'cmvae_conv_gemm': (c_int, [_PG, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p]),
+    'cmvae_conv_gemm_bnbwd': (c_int, [_PG] + [c_void_p] * 10),
     'cmvae_conv_gemm_multi_grid': (c_int, []),
     'cmvae_conv_gemm_multi': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),

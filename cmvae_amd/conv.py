@@ -116,6 +116,15 @@ def conv_gemm(g, A, Wt, out, bias=None, a_scale=None, a_shift=None, act=0, n_col
     return part
 
 
+def conv_gemm_bnbwd(g, A, Wt, out, x, fold):
+    """out = conv_gemm(g, A, Wt) (a data gradient at relu(bn(x))) and, from the same launch's epilogue, the partial
+    BatchNorm-backward sums [grid,128] = {sum g, sum g*xhat} of the layer below; fold = (scale, shift, mean, invstd)."""
+    part = torch.empty(gemm_grid(max(g.rows_total, 1), 1), 128, device=A.device, dtype=torch.float32)
+    check(lib.cmvae_conv_gemm_bnbwd(ctypes.byref(g), _p(A), _p(Wt), _p(out), _p(x), _p(fold[0]), _p(fold[1]),
+                                    _p(fold[2]), _p(fold[3]), _p(part), _stream()), 'cmvae_conv_gemm_bnbwd')
+    return part
+
+
 @functools.lru_cache(maxsize=None)
 def gemm_multi_grid():
     return lib.cmvae_conv_gemm_multi_grid()

@@ -399,14 +399,22 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(ConvGeom g, const flo
 // mse_target != NULL (nn.Linear launches of the feature models' last proj layer): the epilogue also accumulates the
 // squared error of the activated output against target[row / mse_M][column] — the Gaussian likelihood of
 // mimgnet/model.py:391 — into stats_part's column sums instead of the BatchNorm statistics.
-template <int ACT, bool LINEAR, bool PM>
+// BNB (data-gradient launches of the decoder): the output is the gradient at a = relu(bn(x)); the epilogue reads x at
+// the output's own pixels and leaves in stats_part the BatchNorm-backward sums of the layer below instead of the
+// forward statistics: {sum g, sum g * xhat} per channel, g = out * (x*scale + shift > 0), xhat = (x - mean) * invstd
+// (what bn_relu_bwd_reduce_kernel computes in a pass of its own over out and x).
+struct BnBwd {
+    const float* x;          // [pixels][o_pitch], the layout of out
+    const float* scale; const float* shift; const float* mean; const float* invstd;     // [64] each
+};
+template <int ACT, bool LINEAR, bool PM, bool BNB = false>
 __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, const float* __restrict__ A,
                                                                   const float* __restrict__ Wt,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out,
                                                                   float* __restrict__ stats_part,
                                                                   const float* __restrict__ mse_target, int mse_M,
-                                                                  int mse_pitch) {
+                                                                  int mse_pitch, BnBwd bnb = BnBwd{}) {
     __shared__ __align__(16) float Ws[64 * LDA];
     __shared__ int opix[2][BM];
     __shared__ float red[4 * 128];
@@ -421,6 +429,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
     float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
     const float b0 = bias ? bias[nb * 64 + i] : 0.f;
     const float b1 = bias ? bias[nb * 64 + 32 + i] : 0.f;
+    float bsc0 = 0.f, bsh0 = 0.f, bmu0 = 0.f, bis0 = 0.f, bsc1 = 0.f, bsh1 = 0.f, bmu1 = 0.f, bis1 = 0.f;
+    if (BNB) {
+        bsc0 = bnb.scale[i]; bsh0 = bnb.shift[i]; bmu0 = bnb.mean[i]; bis0 = bnb.invstd[i];
+        bsc1 = bnb.scale[32 + i]; bsh1 = bnb.shift[32 + i]; bmu1 = bnb.mean[32 + i]; bis1 = bnb.invstd[32 + i];
+    }
 
     RowInfo ri;
     // two operand register sets used alternately (the loop body is instantiated twice): the loads of step s+1 go
@@ -557,6 +570,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
                         const float e0 = y0 - tg[i], e1 = y1 - tg[32 + i];
                         ssum0 = fmaf(e0, e0, ssum0);
                         ssum1 = fmaf(e1, e1, ssum1);
+                    } else if (BNB) {
+                        const float* xr = bnb.x + (long)op * g.o_pitch;
+                        const float x0 = xr[i], x1 = xr[32 + i];
+                        const float g0 = fmaf(x0, bsc0, bsh0) > 0.f ? v0 : 0.f;
+                        const float g1 = fmaf(x1, bsc1, bsh1) > 0.f ? v1 : 0.f;
+                        ssum0 += g0; ssq0 = fmaf(g0, (x0 - bmu0) * bis0, ssq0);
+                        ssum1 += g1; ssq1 = fmaf(g1, (x1 - bmu1) * bis1, ssq1);
                     } else {
                         ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
                         ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
@@ -603,12 +623,12 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 constexpr int WSTAT_TAPS4 = 4, WSTAT_TAPS8 = 9;
 // bid / nblk: the workgroup's index among the workgroups that share this geometry (a launch may run several
 // geometries side by side: conv_gemm_wstat_multi_kernel); stats_bid / stats_nblk: its index in the whole launch.
-template <int ACT, bool HAS_T, int NW, bool PM>
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false>
 __device__ __forceinline__ void wstat_body(
     const ConvGeom& g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
     float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps, int bid, int nblk, int nb_in, int stats_bid,
-    int stats_nblk) {
+    int stats_nblk, const BnBwd& bnb = BnBwd{}) {
     constexpr int BMT = 32 * NW;                                   // rows per tile: 32 per wave
     extern __shared__ __align__(16) float wstat_smem[];
     float* Ws = wstat_smem;                                        // [ntaps][64][LDA]
@@ -640,6 +660,11 @@ __device__ __forceinline__ void wstat_body(
     floatx2 sum0p = {0.f, 0.f}, sum1p = sum0p, sq0p = sum0p, sq1p = sum0p;      // fast epilogue: sums over even / odd rows
     const float b0 = bias ? bias[nb * 64 + i] : 0.f;
     const float b1 = bias ? bias[nb * 64 + 32 + i] : 0.f;
+    float bsc0 = 0.f, bsh0 = 0.f, bmu0 = 0.f, bis0 = 0.f, bsc1 = 0.f, bsh1 = 0.f, bmu1 = 0.f, bis1 = 0.f;
+    if (BNB) {
+        bsc0 = bnb.scale[i]; bsh0 = bnb.shift[i]; bmu0 = bnb.mean[i]; bis0 = bnb.invstd[i];
+        bsc1 = bnb.scale[32 + i]; bsh1 = bnb.shift[32 + i]; bmu1 = bnb.mean[32 + i]; bis1 = bnb.invstd[32 + i];
+    }
     // uniform: every output byte offset fits 32 bits and every pixel index 24 (v_mad_u32_u24)
     const bool out_off32 = (long)(g.rows_total / (g.Hg * g.Wg)) * g.Ho * g.Wo < (1L << 24) &&
                            (long)(g.rows_total / (g.Hg * g.Wg)) * g.Ho * g.Wo * g.o_pitch * 4 < (1L << 32) &&
@@ -739,6 +764,7 @@ __device__ __forceinline__ void wstat_body(
             const floatx2 bb0 = {b0, b0}, bb1 = {b1, b1};
             const unsigned col_b = (unsigned)(nb * 64 + i) * 4u, pitch_b = (unsigned)g.o_pitch * 4u;
             const char* ob = reinterpret_cast<const char*>(out);
+            const char* xb = reinterpret_cast<const char*>(bnb.x);
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const int4 ops = *reinterpret_cast<const int4*>(&op_w[8 * rq + 4 * h]);
@@ -747,8 +773,21 @@ __device__ __forceinline__ void wstat_body(
                 for (int r = 0; r < 4; r += 2) {
                     const floatx2 v0 = floatx2{acc0[4 * rq + r], acc0[4 * rq + r + 1]} + bb0;
                     const floatx2 v1 = floatx2{acc1[4 * rq + r], acc1[4 * rq + r + 1]} + bb1;
-                    sum0p += v0; sq0p = __builtin_elementwise_fma(v0, v0, sq0p);
-                    sum1p += v1; sq1p = __builtin_elementwise_fma(v1, v1, sq1p);
+                    if (BNB) {
+                        const float* x0 = (const float*)(xb + (__umul24((unsigned)opv[r], pitch_b) + col_b));
+                        const float* x1 = (const float*)(xb + (__umul24((unsigned)opv[r + 1], pitch_b) + col_b));
+                        const floatx2 xa = {x0[0], x1[0]}, xc = {x0[32], x1[32]};
+                        const floatx2 ma = __builtin_elementwise_fma(xa, floatx2{bsc0, bsc0}, floatx2{bsh0, bsh0});
+                        const floatx2 mc = __builtin_elementwise_fma(xc, floatx2{bsc1, bsc1}, floatx2{bsh1, bsh1});
+                        const floatx2 g0 = {ma.x > 0.f ? v0.x : 0.f, ma.y > 0.f ? v0.y : 0.f};
+                        const floatx2 g1 = {mc.x > 0.f ? v1.x : 0.f, mc.y > 0.f ? v1.y : 0.f};
+                        sum0p += g0; sum1p += g1;
+                        sq0p = __builtin_elementwise_fma(g0, (xa - floatx2{bmu0, bmu0}) * floatx2{bis0, bis0}, sq0p);
+                        sq1p = __builtin_elementwise_fma(g1, (xc - floatx2{bmu1, bmu1}) * floatx2{bis1, bis1}, sq1p);
+                    } else {
+                        sum0p += v0; sq0p = __builtin_elementwise_fma(v0, v0, sq0p);
+                        sum1p += v1; sq1p = __builtin_elementwise_fma(v1, v1, sq1p);
+                    }
 #if !(CMVAE_ABLATE == 12 || CMVAE_ABLATE == 13)
                     float* o0 = (float*)(ob + (__umul24((unsigned)opv[r], pitch_b) + col_b));
                     float* o1 = (float*)(ob + (__umul24((unsigned)opv[r + 1], pitch_b) + col_b));
@@ -770,8 +809,17 @@ __device__ __forceinline__ void wstat_body(
                 if (op >= 0) {
                     float* o = out + (long)op * g.o_pitch + nb * 64;
                     const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
-                    ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
-                    ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
+                    if (BNB) {
+                        const float* xr = bnb.x + (long)op * g.o_pitch + nb * 64;
+                        const float x0 = xr[i], x1 = xr[32 + i];
+                        const float g0 = fmaf(x0, bsc0, bsh0) > 0.f ? v0 : 0.f;
+                        const float g1 = fmaf(x1, bsc1, bsh1) > 0.f ? v1 : 0.f;
+                        ssum0 += g0; ssq0 = fmaf(g0, (x0 - bmu0) * bis0, ssq0);
+                        ssum1 += g1; ssq1 = fmaf(g1, (x1 - bmu1) * bis1, ssq1);
+                    } else {
+                        ssum0 += v0; ssq0 = fmaf(v0, v0, ssq0);
+                        ssum1 += v1; ssq1 = fmaf(v1, v1, ssq1);
+                    }
 #if CMVAE_ABLATE == 12 || CMVAE_ABLATE == 13     // no output stores (the statistics keep the accumulators alive)
                     if (v0 == 1.2345e33f) o[i] = v1;
 #else
@@ -810,13 +858,14 @@ __device__ __forceinline__ void wstat_body(
     }
 }
 
-template <int ACT, bool HAS_T, int NW, bool PM>
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kernel(
     ConvGeom g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
-    float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps) {
-    wstat_body<ACT, HAS_T, NW, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps,
-                                   (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+    float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps, BnBwd bnb = BnBwd{}) {
+    wstat_body<ACT, HAS_T, NW, PM, BNB>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps,
+                                        (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.x,
+                                        (int)gridDim.x, bnb);
 }
 
 // Up to four geometries over the same operand, weight and output tensors in ONE launch — the sub-pixel phases of a
@@ -839,13 +888,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_wstat_multi_kernel(
                                   b - p.begin[ph], p.begin[ph + 1] - p.begin[ph], 0, b, (int)gridDim.x);
 }
 
-template <int ACT, bool HAS_T, int NW, bool PM>
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false>
 static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, const float* bias, const float* a_scale,
                         const float* a_shift, float* out, float* stats_part, int stats_rows, int n_col_blocks,
-                        int tap0, int ntaps, hipStream_t st) {
+                        int tap0, int ntaps, hipStream_t st, BnBwd bnb = BnBwd{}) {
     const size_t lds = (size_t)ntaps * 64 * LDA * sizeof(float) + 2 * NW * 32 * sizeof(int) + NW * 128 * sizeof(float);
     static const bool opted = [] {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM>,
+        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         return true;
@@ -853,13 +902,13 @@ static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, cons
     (void)opted;
     const int ntiles = (g.rows_total + 32 * NW - 1) / (32 * NW);
     // resident workgroups: two (NW = 4) or one (NW = 8) per CU
-    static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM>, 64 * NW,
+    static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB>, 64 * NW,
                                            (NW == 4 ? 2 : 1) * compute_units());
     const int most = (NW == 4 ? 2 : 1) * compute_units();
     const int cap_use = cap < most ? cap : most;
     const dim3 grid(ntiles < cap_use ? ntiles : cap_use, n_col_blocks);
-    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
-                       a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps);
+    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
+                       a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps, bnb);
     return check_launch("conv_gemm_wstat_kernel");
 }
 
@@ -1545,6 +1594,33 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     }
 #undef CMVAE_LAUNCH_GEMM
     return check_launch("conv_gemm_kernel");
+}
+
+extern "C" int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A, const float* Wt, float* out,
+                                     const float* x, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, float* sums_part, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(geom && A && Wt && out && x && scale && shift && mean && invstd && sums_part,
+                  "cmvae_conv_gemm_bnbwd: NULL argument");
+    ConvGeom g = to_geom(geom);
+    if (int e = check_geom(g)) return e;
+    CMVAE_REQUIRE(g.o_pitch == 64, "cmvae_conv_gemm_bnbwd: the output (and x) must be [pixels, 64]");
+    const int gx = gemm_grid(g.rows_total > 0 ? g.rows_total : 1, 1);
+    if (g.rows_total == 0) {
+        (void)hipMemsetAsync(sums_part, 0, (size_t)gx * 128 * sizeof(float), (hipStream_t)stream);
+        return check_launch("cmvae_conv_gemm_bnbwd (empty)");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const BnBwd bnb{x, scale, shift, mean, invstd};
+    const float* none = nullptr;
+    if (g.pm_nimg > 0 && g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256)
+        return launch_wstat<0, false, 8, true, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, 0, g.ntaps, st, bnb);
+    const dim3 grid(gx, 1);
+    if (g.pm_nimg > 0)
+        hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, true, true>), grid, dim3(256), 0, st, g, A, Wt, none, out, sums_part, none, 1, 0, bnb);
+    else
+        hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, false, true>), grid, dim3(256), 0, st, g, A, Wt, none, out, sums_part, none, 1, 0, bnb);
+    return check_launch("conv_gemm_direct_kernel (bn backward sums)");
 }
 
 extern "C" size_t cmvae_conv_wgrad_workspace_bytes(int rows_total) {

@@ -118,6 +118,9 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
 # CMVAE_CONV_MULTI=0: one launch per sub-pixel phase of a transposed conv instead of one per layer (A/B measurements)
 MULTI_PHASE = os.environ.get('CMVAE_CONV_MULTI', '1') not in ('', '0')
 
+# CMVAE_FUSED_BN_SUMS=0: the BatchNorm-backward sums in a pass of their own instead of the data gradient's epilogue
+FUSED_BN_SUMS = os.environ.get('CMVAE_FUSED_BN_SUMS', '1') not in ('', '0')
+
 # CMVAE_BN_SIDE=1: the decoder's BatchNorm backward passes on a side stream next to the weight-gradient GEMMs (off by
 # default: measured slower inside the step, see _DecoderBCE.backward)
 BN_SIDE_STREAM = os.environ.get('CMVAE_BN_SIDE', '0') not in ('', '0')
@@ -207,11 +210,17 @@ class _DecoderBCE(torch.autograd.Function):
             gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=PIXEL_MAJOR)
             wtd = ws[li].detach().permute(2, 3, 0, 1).contiguous()   # [ky][kx][ci][co]
             d_in = torch.empty(n * Hi * Hi, 64, device=dev)
-            conv.conv_gemm(gd, dy, wtd, d_in)
+            fused_sums = None
+            if li > 0 and FUSED_BN_SUMS:
+                # the BatchNorm-backward sums of the layer below come out of the data gradient's epilogue
+                fused_sums = colsum(conv.conv_gemm_bnbwd(gd, dy, wtd, d_in, x_in, fold_in))
+            else:
+                conv.conv_gemm(gd, dy, wtd, d_in)
             dy_below = None
             if li > 0:
                 def bn_below():
-                    sums_b = bn_relu_bwd_sums(d_in, x_in, fold_in, masked=False)
+                    sums_b = fused_sums if fused_sums is not None else \
+                        bn_relu_bwd_sums(d_in, x_in, fold_in, masked=False)
                     c1b, c2b, dg, dbe = bn_bwd_finalize(sums_b, x_in.shape[0])
                     grads_g[li - 1], grads_be[li - 1] = dg, dbe
                     return bn_relu_bwd_apply(d_in, x_in, fold_in, c1b, c2b, False, out=d_in)     # in place

@@ -230,6 +230,16 @@ _d.define('conv_gemm_multi(int[] geoms, Tensor A, Tensor Wt, Tensor(a!) out, Ten
           'Tensor? a_shift, bool stats) -> Tensor')
 _d.define('conv_wgrad_multi(int[] geoms, Tensor A, Tensor G, Tensor(a!) dW, int[] tap_off, int s_ci, int s_co, '
           'Tensor(b!)? db, Tensor? a_scale, Tensor? a_shift, int g_pitch) -> ()')
+_d.define('conv_gemm_bnbwd(int[] geom, Tensor A, Tensor Wt, Tensor(a!) out, Tensor x, Tensor scale, Tensor shift, '
+          'Tensor mean, Tensor invstd) -> Tensor')
+
+
+def _conv_gemm_bnbwd(geom, A, Wt, out, x, scale, shift, mean, invstd):
+    for t, n in ((A, 'A'), (Wt, 'Wt'), (out, 'out'), (x, 'x')):
+        linear._need(t, n)
+    if x.shape != out.shape or not x.is_contiguous() or any(t.numel() != 64 for t in (scale, shift, mean, invstd)):
+        raise RuntimeError('cmvae_amd: conv_gemm_bnbwd takes x in the layout of out and four [64] fold vectors')
+    return conv.conv_gemm_bnbwd(geom_from_list(geom), A, Wt, out, x, (scale, shift, mean, invstd))
 
 
 def _geoms_from_list(vals):
@@ -282,6 +292,7 @@ for _name, _fn in (('unsup_prior', _unsup_prior), ('semi_prior', _semi_prior), (
                    ('attention_bwd', _attention_bwd), ('adam_step', _adam_step), ('conv_gemm', _conv_gemm),
                    ('attention_qkv_fwd', _attention_qkv_fwd), ('attention_qkv_bwd', _attention_qkv_bwd),
                    ('conv_wgrad', _conv_wgrad), ('conv_gemm_multi', _conv_gemm_multi),
+                   ('conv_gemm_bnbwd', _conv_gemm_bnbwd),
                    ('conv_wgrad_multi', _conv_wgrad_multi)):
     _d.impl(_name, _fn, 'CUDA')
 
@@ -289,7 +300,7 @@ REGISTERED = ('mixture_loglik_fwd', 'mixture_loglik_bwd', 'reparam_logq_fwd', 'r
               'unsup_prior', 'semi_prior', 'posterior_argmax', 'causal_rows', 'gram_inverse', 'center_rows',
               'linear_fwd', 'linear_bwd', 'linear_mse_fwd', 'mse_act_bwd', 'act_bwd', 'attention_fwd', 'attention_bwd',
               'adam_step', 'conv_gemm', 'conv_wgrad', 'conv_gemm_multi', 'conv_wgrad_multi', 'attention_qkv_fwd',
-              'attention_qkv_bwd')
+              'attention_qkv_bwd', 'conv_gemm_bnbwd')
 
 
 # ----------------------------------------------------------------------------- whole encoder / decoder

@@ -180,6 +180,15 @@ int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks);
 int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, const float* Wt, const float* bias,
                     const float* a_scale, const float* a_shift, int act, int n_col_blocks,
                     float* out, float* stats_part, void* stream);
+/* Data gradient of a decoder layer with the BatchNorm-backward sums of the layer below from the epilogue
+ * (backward of ConvTranspose2d -> BatchNorm2d -> ReLU, omniglot/module.py:50-58): out = conv_gemm(geom, A, Wt) is the
+ * gradient at a = relu(bn(x)); x [pixels,64] is read at out's own pixels and
+ * sums_part [cmvae_conv_gemm_grid(rows,1)][128] receives per-workgroup partials of
+ * {sum g[64], sum g*xhat[64]}, g = out * (x*scale + shift > 0), xhat = (x - mean) * invstd
+ * (= cmvae_bn_relu_bwd_reduce(out, x, ...) without its pass over out and x).  No bias, no activation.          */
+int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A, const float* Wt, float* out, const float* x,
+                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                          float* sums_part, void* stream);
 /* Up to four geometries over the same operand, weight and output tensors in one launch: the sub-pixel phases of a
  * ConvTranspose2d(64,64,k,2,1) (omniglot/module.py:50-58), each with at most 4 taps, identity activation, one
  * 64-column block, all in the same row order.  stats_part (or NULL): [cmvae_conv_gemm_multi_grid()][128] partial

@@ -130,6 +130,22 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
     da = torch.empty(n * Hi * Hi, 64, device=device)
     conv.conv_gemm(gd, gyd, wtd, da)
     assert rel_err(from_nhwc(da.cpu(), n, Hi, Hi), a.grad) < TOL
+    # the data gradient with the BatchNorm-backward sums of the layer below from its epilogue: the same gradient bit
+    # for bit, the sums of bn_relu_bwd_sums (a pass of its own over the gradient and x) to rounding
+    from cmvae_amd import decoder
+    mean = torch.randn(64, generator=g) * 0.2
+    invstd = torch.rand(64, generator=g) + 0.5
+    fold = tuple(t.to(device) for t in (sc, sh, mean, invstd))
+    da3 = torch.full_like(da, float('nan'))
+    part = conv.conv_gemm_bnbwd(gd, gyd, wtd, da3, xd, fold)
+    assert torch.equal(da3, da)
+    want = decoder.bn_relu_bwd_sums(da, xd, fold, masked=False)
+    got = decoder.colsum(part)
+    assert rel_err(got[:64], want[:64]) < 1e-5 and rel_err(got[64:], want[64:]) < 1e-5
+    m64 = (xd.double().cpu() * sc.double() + sh.double()) > 0
+    g64 = da.double().cpu() * m64
+    ref = torch.cat([g64.sum(0), (g64 * (xd.double().cpu() - mean.double()) * invstd.double()).sum(0)])
+    assert rel_err(got.cpu(), ref.float()) < 1e-5
     if pm:
         # the same per-row sums in the same tap order: forward and data gradient agree bit for bit with the
         # image-major launches (also without a folded BatchNorm, as in the decoder's first layer)
@@ -147,6 +163,29 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
         da2 = torch.empty_like(da)
         conv.conv_gemm(conv.geom_convT_dgrad(n, Hi, Hi, k)[0], gyd, wtd, da2)
         assert torch.equal(da, da2)
+
+
+def test_dgrad_bn_sums_epilogue_weight_stationary_kernel(device):
+    """Layer-2 shape of the training step (9-tap data gradient, >= 196608 rows: the eight-wave weight-stationary
+    kernel): gradient bit-equal to the plain launch, sums equal to the separate reduction pass."""
+    from cmvae_amd import conv, decoder
+    n, Hi, k = 12304, 4, 3
+    Ho = conv.convT_out(Hi, k)
+    g = torch.Generator().manual_seed(5)
+    gy = torch.randn(n * Ho * Ho, 64, generator=g).to(device)
+    x = torch.randn(n * Hi * Hi, 64, generator=g).to(device)
+    wtd = (torch.randn(k, k, 64, 64, generator=g) * 0.1).to(device)
+    fold = tuple(t.to(device) for t in (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3,
+                                        torch.randn(64, generator=g) * 0.2, torch.rand(64, generator=g) + 0.5))
+    gd, _ = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=True)
+    want = torch.empty(n * Hi * Hi, 64, device=device)
+    conv.conv_gemm(gd, gy, wtd, want)
+    got = torch.full_like(want, float('nan'))
+    part = conv.conv_gemm_bnbwd(gd, gy, wtd, got, x, fold)
+    assert torch.equal(got, want)
+    s_want = decoder.bn_relu_bwd_sums(want, x, fold, masked=False)
+    s_got = decoder.colsum(part)
+    assert rel_err(s_got[:64], s_want[:64]) < 1e-5 and rel_err(s_got[64:], s_want[64:]) < 1e-5
 
 
 def test_multi_launch_rejects_what_it_cannot_run(device):

@@ -140,6 +140,16 @@ def test_conv_ops_take_the_geometry_as_a_list(device):
     conv.conv_wgrad_multi(geoms, x, gy4, dWw, [t for _, t in phases], 64 * k * k, k * k, db=dbw)
     O.conv_wgrad_multi(flat, x, gy4, dWg, [t for _, ts in phases for t in ts], 64 * k * k, k * k, dbg, None, None, 64)
     assert torch.equal(dWw, dWg) and torch.equal(dbw, dbg)
+    # data gradient with the BatchNorm-backward sums of the layer below from its epilogue
+    gd, _ = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=True)
+    wtd = (torch.randn(k, k, 64, 64, generator=g) * 0.1).to(device)
+    fold = [torch.rand(64, generator=g).to(device) + 0.5 for _ in range(4)]
+    dw, dg_ = torch.empty(n * Hi * Hi, 64, device=device), torch.empty(n * Hi * Hi, 64, device=device)
+    pw = conv.conv_gemm_bnbwd(gd, gy4, wtd, dw, x, fold)
+    pg = O.conv_gemm_bnbwd(geom_to_list(gd), gy4, wtd, dg_, x, *fold)
+    assert torch.equal(dw, dg_) and torch.equal(pw, pg)
+    with pytest.raises(RuntimeError):
+        O.conv_gemm_bnbwd(geom_to_list(gd), gy4, wtd, dg_, x[:-1], *fold)
     with pytest.raises(RuntimeError):
         O.conv_gemm_multi(flat[:-1], x, wt4, got, b, None, None, False)
     with pytest.raises(RuntimeError):
