@@ -904,7 +904,9 @@ static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, cons
     // resident workgroups: two (NW = 4) or one (NW = 8) per CU
     static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB>, 64 * NW,
                                            (NW == 4 ? 2 : 1) * compute_units());
-    const int most = (NW == 4 ? 2 : 1) * compute_units();
+    // (nn.Linear launches: the column blocks share the resident workgroups)
+    int most = (NW == 4 ? 2 : 1) * compute_units() / (n_col_blocks > 0 ? n_col_blocks : 1);
+    if (most < 1) most = 1;
     const int cap_use = cap < most ? cap : most;
     const dim3 grid(ntiles < cap_use ? ntiles : cap_use, n_col_blocks);
     hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
@@ -1834,9 +1836,27 @@ static ConvGeom linear_geom(int rows, int K, int N, int a_pitch, int o_pitch) {
     return g;
 }
 
+// CMVAE_LINEAR_WSTAT=0 keeps every nn.Linear launch on the direct kernel (A/B measurements)
+static bool linear_wstat_enabled() {
+    static const bool on = [] { const char* e = getenv("CMVAE_LINEAR_WSTAT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const float* bias, int act, int ncb,
                        float* out, hipStream_t st, const float* mse_target = nullptr, int mse_M = 1, int mse_pitch = 0,
                        float* mse_part = nullptr) {
+    // in_features = 64 into many column blocks over many rows (fc1 of the NOTEARS-MLP layer, 64 -> 2048): a step of the
+    // direct kernel would be one 64-deep tap between two barriers; here a workgroup keeps its column block's weight
+    // tile in LDS and walks the row tiles without a barrier (147 vs 176 us on [38400, 64]).  Measured slower or equal
+    // for in_features = 256 (68 vs 66 us) and for the small launches (17-19 vs 15 us), which stay on the direct kernel.
+    if (!mse_target && g.ntaps == 1 && ncb >= 8 && g.rows_total >= 8192 && linear_wstat_enabled()) {
+        const float* none = nullptr;
+        switch (act) {
+            case 0: return launch_wstat<0, false, 4, false>(g, A, Wt, bias, none, none, out, nullptr, 0, ncb, 0, g.ntaps, st);
+            case 1: return launch_wstat<1, false, 4, false>(g, A, Wt, bias, none, none, out, nullptr, 0, ncb, 0, g.ntaps, st);
+            default: return launch_wstat<2, false, 4, false>(g, A, Wt, bias, none, none, out, nullptr, 0, ncb, 0, g.ntaps, st);
+        }
+    }
     dim3 grid(gemm_grid(g.rows_total, ncb), ncb);
     switch (act) {
         case 0: hipLaunchKernelGGL((conv_gemm_direct_kernel<0, true, false>), grid, dim3(256), 0, st, g, A, Wt, bias, out, mse_part, mse_target, mse_M, mse_pitch); break;
