@@ -64,6 +64,14 @@ SIGNATURES = {
     'cmvae_reparam_logq_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p]),
     'cmvae_expm_trace': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_elbo_tail_blocks': (c_int, []),
+    'cmvae_elbo_tail_fwd': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                    c_int64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    'cmvae_elbo_tail_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_int64,
+                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+    'cmvae_prior_logw_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'cmvae_prior_logw_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'cmvae_colsum_reduce': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_bn_finalize': (c_int, [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -489,3 +489,173 @@ extern "C" int cmvae_adam_step_dev(float* param, const float* grad, float* exp_a
                        (const long long*)step_dev, lr, beta1, beta2, eps, weight_decay);
     return cmvae::check_launch("adam_devstep_kernel");
 }
+
+// ============================================================================ ELBO tail
+// The scalar tail of GMVAE.forward (omniglot/model.py:468-489) in two launches instead of ~25 ATen ones, and its
+// backward in one instead of ~30:
+//   kl    = mean(log_q_z) - mean(log_p_z) - mean_rows(glp(q_eps, 0))        glp(x,0) = sum_d(-0.5 x_d^2 + c)
+//   h_aug = h_lambda * h + 0.5 * h_c * h^2 + a_lambda * sum|A|
+// and the prior log-weights of the mixture term (:455-461),
+//   logw[b,k] = log(pi[b,k]) + glp(x[b,k,:], mean = log(trace[b,k]), logvar = 0)
+// (the reference passes log(trace_k) in gaussian_log_prob's MEAN slot, :483-490, and so does this)
+namespace cmvae {
+
+constexpr int TAIL_BLOCKS = 256;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// part[blk] = {sum log_q, sum log_p, sum q_eps^2, sum |A|} over the block's grid-stride share (fixed order)
+__global__ __launch_bounds__(256) void elbo_tail_partial_kernel(const float* __restrict__ logq, long n1,
+                                                                const float* __restrict__ logp, long n2,
+                                                                const float4* __restrict__ qeps4, long n3,
+                                                                const float* __restrict__ A, long nA,
+                                                                float* __restrict__ part) {
+    __shared__ float red[4];
+    const long t = (long)blockIdx.x * 256 + threadIdx.x, T = (long)gridDim.x * 256;
+    float s0 = 0.f, s1 = 0.f, s3 = 0.f;
+    float q0 = 0.f, q1 = 0.f;
+    for (long e = t; e < n1; e += T) s0 += logq[e];
+    for (long e = t; e < n2; e += T) s1 += logp[e];
+    long e = t;
+    for (; e + T < n3; e += 2 * T) {
+        const float4 a = qeps4[e], b = qeps4[e + T];
+        q0 = fmaf(a.x, a.x, q0); q0 = fmaf(a.y, a.y, q0); q0 = fmaf(a.z, a.z, q0); q0 = fmaf(a.w, a.w, q0);
+        q1 = fmaf(b.x, b.x, q1); q1 = fmaf(b.y, b.y, q1); q1 = fmaf(b.z, b.z, q1); q1 = fmaf(b.w, b.w, q1);
+    }
+    if (e < n3) {
+        const float4 a = qeps4[e];
+        q0 = fmaf(a.x, a.x, q0); q0 = fmaf(a.y, a.y, q0); q0 = fmaf(a.z, a.z, q0); q0 = fmaf(a.w, a.w, q0);
+    }
+    for (long k = t; k < nA; k += T) s3 += fabsf(A[k]);
+    const float r0 = block_sum_256(s0, red), r1 = block_sum_256(s1, red), r2 = block_sum_256(q0 + q1, red),
+                r3 = block_sum_256(s3, red);
+    if (threadIdx.x == 0) {
+        float* p = part + 4 * blockIdx.x;
+        p[0] = r0; p[1] = r1; p[2] = r2; p[3] = r3;
+    }
+}
+
+// out = {kl, h_aug}
+__global__ __launch_bounds__(256) void elbo_tail_final_kernel(const float* __restrict__ part, int nblk,
+                                                              const float* __restrict__ h, float n1, float n2,
+                                                              float rows, float dim, float h_lambda, float h_c,
+                                                              float a_lambda, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += part[4 * b + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = block_sum_256(s[k], red);
+    if (threadIdx.x == 0) {
+        const float hv = h[0];
+        const float log_p_eps_mean = -0.5f * s[2] / rows + dim * LOG_NORM;
+        out[0] = s[0] / n1 - s[1] / n2 - log_p_eps_mean;
+        out[1] = h_lambda * hv + 0.5f * h_c * hv * hv + a_lambda * s[3];
+    }
+}
+
+// g = {d kl, d h_aug} (device scalars):  d log_q = g0/n1, d log_p = -g0/n2, d q_eps = g0 * q_eps / rows,
+// dA = g1 * a_lambda * sign(A), dh = g1 * (h_lambda + h_c * h)
+__global__ __launch_bounds__(256) void elbo_tail_bwd_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                            const float4* __restrict__ qeps4, long n3,
+                                                            const float* __restrict__ A, long nA, long n1, long n2,
+                                                            float rows, float h_lambda, float h_c, float a_lambda,
+                                                            float* __restrict__ d_logq, float* __restrict__ d_logp,
+                                                            float4* __restrict__ d_qeps4, float* __restrict__ dA,
+                                                            float* __restrict__ dh) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x, T = (long)gridDim.x * 256;
+    const float g0 = g[0], g1 = g[1];
+    const float a = g0 / (float)n1, b = -g0 / (float)n2, c = g0 / rows;
+    for (long e = t; e < n1; e += T) d_logq[e] = a;
+    for (long e = t; e < n2; e += T) d_logp[e] = b;
+    for (long e = t; e < n3; e += T) {
+        const float4 v = qeps4[e];
+        d_qeps4[e] = make_float4(c * v.x, c * v.y, c * v.z, c * v.w);
+    }
+    for (long k = t; k < nA; k += T) {
+        const float v = A[k];
+        dA[k] = g1 * a_lambda * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f));
+    }
+    if (t == 0) dh[0] = g1 * (h_lambda + h_c * h[0]);
+}
+
+// logw[r] = log(pi[r]) + sum_d(-0.5 * (x[r][d] - lt)^2 + c),  lt = log(trace[r]);  one wave per row, D = 64
+__global__ __launch_bounds__(64) void prior_logw_fwd_kernel(const float* __restrict__ pi, const float* __restrict__ trace,
+                                                            const float* __restrict__ x, float* __restrict__ logw) {
+    const int r = blockIdx.x, d = threadIdx.x;
+    const float lt = logf(trace[r]);
+    const float v = x[(long)r * 64 + d] - lt;
+    float p = -0.5f * (v * v) + LOG_NORM;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+    if (d == 0) logw[r] = logf(pi[r]) + p;
+}
+
+// dx[r][d] = -g[r] * (x[r][d] - log(trace[r]))
+__global__ __launch_bounds__(64) void prior_logw_bwd_kernel(const float* __restrict__ trace, const float* __restrict__ x,
+                                                            const float* __restrict__ g, float* __restrict__ dx) {
+    const int r = blockIdx.x, d = threadIdx.x;
+    dx[(long)r * 64 + d] = -g[r] * (x[(long)r * 64 + d] - logf(trace[r]));
+}
+
+}  // namespace cmvae
+
+extern "C" int cmvae_elbo_tail_blocks(void) { cmvae::clear_stale_error(); return cmvae::TAIL_BLOCKS; }
+
+extern "C" int cmvae_elbo_tail_fwd(const float* log_q, int64_t n1, const float* log_p, int64_t n2, const float* q_eps,
+                                   int64_t rows, int dim, const float* h, const float* A, int64_t nA, float h_lambda,
+                                   float h_c, float a_lambda, float* part, float* out, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(log_q && log_p && q_eps && h && A && part && out, "cmvae_elbo_tail_fwd: NULL argument");
+    CMVAE_REQUIRE(n1 >= 1 && n2 >= 1 && rows >= 1 && dim >= 4 && dim % 4 == 0 && nA >= 0,
+                  "cmvae_elbo_tail_fwd: empty tensor or latent size not a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cmvae::elbo_tail_partial_kernel, dim3(cmvae::TAIL_BLOCKS), dim3(256), 0, st, log_q, (long)n1, log_p,
+                       (long)n2, (const float4*)q_eps, (long)(rows * dim / 4), A, (long)nA, part);
+    if (int e = cmvae::check_launch("elbo_tail_partial_kernel")) return e;
+    hipLaunchKernelGGL(cmvae::elbo_tail_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, cmvae::TAIL_BLOCKS, h,
+                       (float)n1, (float)n2, (float)rows, (float)dim, h_lambda, h_c, a_lambda, out);
+    return cmvae::check_launch("elbo_tail_final_kernel");
+}
+
+extern "C" int cmvae_elbo_tail_bwd(const float* g, const float* h, const float* q_eps, int64_t rows, int dim,
+                                   const float* A, int64_t nA, int64_t n1, int64_t n2, float h_lambda, float h_c,
+                                   float a_lambda, float* d_log_q, float* d_log_p, float* d_q_eps, float* dA, float* dh,
+                                   void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(g && h && q_eps && A && d_log_q && d_log_p && d_q_eps && dA && dh, "cmvae_elbo_tail_bwd: NULL argument");
+    CMVAE_REQUIRE(n1 >= 1 && n2 >= 1 && rows >= 1 && dim >= 4 && dim % 4 == 0 && nA >= 0,
+                  "cmvae_elbo_tail_bwd: empty tensor or latent size not a multiple of 4");
+    const long n3 = rows * dim / 4;
+    hipLaunchKernelGGL(cmvae::elbo_tail_bwd_kernel, dim3(cmvae::grid_for(n3, 256)), dim3(256), 0, (hipStream_t)stream, g, h,
+                       (const float4*)q_eps, n3, A, (long)nA, (long)n1, (long)n2, (float)rows, h_lambda, h_c, a_lambda,
+                       d_log_q, d_log_p, (float4*)d_q_eps, dA, dh);
+    return cmvae::check_launch("elbo_tail_bwd_kernel");
+}
+
+extern "C" int cmvae_prior_logw_fwd(const float* pi, const float* trace, const float* x, int rows, float* logw,
+                                    void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(pi && trace && x && logw && rows >= 0, "cmvae_prior_logw_fwd: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(cmvae::prior_logw_fwd_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, pi, trace, x, logw);
+    return cmvae::check_launch("prior_logw_fwd_kernel");
+}
+
+extern "C" int cmvae_prior_logw_bwd(const float* trace, const float* x, const float* g, int rows, float* dx,
+                                    void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(trace && x && g && dx && rows >= 0, "cmvae_prior_logw_bwd: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(cmvae::prior_logw_bwd_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, trace, x, g, dx);
+    return cmvae::check_launch("prior_logw_bwd_kernel");
+}

@@ -14,6 +14,7 @@ Where the arithmetic runs:
 There is no CPU path: tensors must live on the GPU and the HIP library must be loadable.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -25,6 +26,8 @@ from .linear import linear, linear_mse
 from .decoder import decoder_bce, nhwc_perm, permute
 
 _LOG_NORM = -0.5 * np.log(2 * np.pi)
+# CMVAE_FUSED_TAIL=0: the scalar tail of forward as the chain of ATen kernels (A/B measurements)
+FUSED_TAIL = os.environ.get('CMVAE_FUSED_TAIL', '1') not in ('', '0')
 
 
 class _GMVAEBase(nn.Module):
@@ -131,6 +134,13 @@ class _GMVAEBase(nn.Module):
         pi_k, mu_k, trace_k, _ = self._unsup_prior(q_z, init_idx)
         # prior term with gradient to the causal parameters (mu_k, pi_k, trace_k are constants)
         q_eps_mu_k = self.causal(mu_k)
+        if extras is None and FUSED_TAIL and self.latent_size == 64:
+            # the scalar tail in five launches (forward + backward) instead of ~55 ATen ones
+            logw = ops.prior_logw(pi_k, trace_k, q_eps_mu_k)
+            log_p_z = ops.mixture_loglik(q_z, mu_k, logw)
+            h = self.h_a(A)
+            kl_loss, h_augment = ops.elbo_tail(q_z4_logq, log_p_z, q_eps, h, A, h_lambda, h_c, a_lambda)
+            return kl_loss, h_augment, h
         logw = torch.log(pi_k) + self.gaussian_log_prob(
             q_eps_mu_k, torch.log(trace_k)[:, :, None].expand(-1, -1, self.latent_size))
         log_p_z = ops.mixture_loglik(q_z, mu_k, logw)                      # [B, N]

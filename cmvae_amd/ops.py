@@ -350,3 +350,75 @@ class _ExpmTrace(torch.autograd.Function):
 def expm_trace(A):
     """h(A) = tr(expm(A∘A)) - 64 with dh/dA = expm(A∘A)^T ∘ 2A."""
     return _ExpmTrace.apply(A)
+
+
+class _ElboTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_q, log_p, q_eps, h, A, h_lambda, h_c, a_lambda):
+        log_q, log_p, q_eps, A = (_req(t.contiguous(), n) for t, n in
+                                  ((log_q, 'log_q_z'), (log_p, 'log_p_z'), (q_eps, 'q_eps'), (A, 'A')))
+        dim = q_eps.shape[-1]
+        rows = q_eps.numel() // dim
+        h1 = h.reshape(1).contiguous()
+        part = torch.empty(lib.cmvae_elbo_tail_blocks(), 4, device=q_eps.device, dtype=torch.float32)
+        out = torch.empty(2, device=q_eps.device, dtype=torch.float32)
+        check(lib.cmvae_elbo_tail_fwd(_p(log_q), log_q.numel(), _p(log_p), log_p.numel(), _p(q_eps), rows, dim, _p(h1),
+                                      _p(A), A.numel(), h_lambda, h_c, a_lambda, _p(part), _p(out), _stream()),
+              'cmvae_elbo_tail_fwd')
+        ctx.consts = (float(h_lambda), float(h_c), float(a_lambda), rows, dim)
+        ctx.shapes = (log_q.shape, log_p.shape, h.shape)
+        ctx.save_for_backward(q_eps, h1, A)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_kl, g_h):
+        q_eps, h1, A = ctx.saved_tensors
+        h_lambda, h_c, a_lambda, rows, dim = ctx.consts
+        sq, sp, sh = ctx.shapes
+        dev = q_eps.device
+        zero = torch.zeros((), device=dev)
+        g = torch.stack([zero if g_kl is None else g_kl.reshape(()).float(),
+                         zero if g_h is None else g_h.reshape(()).float()])
+        d_q = torch.empty(sq, device=dev, dtype=torch.float32)
+        d_p = torch.empty(sp, device=dev, dtype=torch.float32)
+        d_e = torch.empty_like(q_eps)
+        dA = torch.empty_like(A)
+        dh = torch.empty(1, device=dev, dtype=torch.float32)
+        check(lib.cmvae_elbo_tail_bwd(_p(g), _p(h1), _p(q_eps), rows, dim, _p(A), A.numel(), d_q.numel(), d_p.numel(),
+                                      h_lambda, h_c, a_lambda, _p(d_q), _p(d_p), _p(d_e), _p(dA), _p(dh), _stream()),
+              'cmvae_elbo_tail_bwd')
+        return d_q, d_p, d_e, dh.reshape(sh), dA, None, None, None
+
+
+def elbo_tail(log_q_z, log_p_z, q_eps, h, A, h_lambda, h_c, a_lambda):
+    """(kl_loss, h_augment) of GMVAE.forward (omniglot/model.py:496-516):
+    kl = mean(log_q_z) - mean(log_p_z) - mean(glp(q_eps, 0)), h_augment = h_lambda h + 0.5 h_c h^2 + a_lambda |A|_1,
+    two launches forward and one backward instead of the chain of scalar ATen kernels."""
+    return _ElboTail.apply(log_q_z, log_p_z, q_eps, h, A, float(h_lambda), float(h_c), float(a_lambda))
+
+
+class _PriorLogW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pi, trace, x):
+        pi, trace, x = _req(pi.contiguous(), 'pi_k'), _req(trace.contiguous(), 'trace_k'), _req(x.contiguous(), 'x')
+        if x.shape[-1] != D or pi.shape != x.shape[:-1] or trace.shape != pi.shape:
+            raise RuntimeError('cmvae_amd: prior_logw takes pi, trace [B,K] and x [B,K,64]')
+        logw = torch.empty_like(pi)
+        check(lib.cmvae_prior_logw_fwd(_p(pi), _p(trace), _p(x), pi.numel(), _p(logw), _stream()),
+              'cmvae_prior_logw_fwd')
+        ctx.save_for_backward(trace, x)
+        return logw
+
+    @staticmethod
+    def backward(ctx, g):
+        trace, x = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        check(lib.cmvae_prior_logw_bwd(_p(trace), _p(x), _p(g.contiguous()), trace.numel(), _p(dx), _stream()),
+              'cmvae_prior_logw_bwd')
+        return None, None, dx
+
+
+def prior_logw(pi_k, trace_k, q_eps_mu_k):
+    """log(pi_k) + gaussian_log_prob(q_eps_mu_k, mean=log(trace_k)) (omniglot/model.py:481-491 — log(trace_k) in the
+    MEAN slot, as the reference has it); the gradient goes to q_eps_mu_k only (pi_k, trace_k: detached EM outputs)."""
+    return _PriorLogW.apply(pi_k.detach(), trace_k.detach(), q_eps_mu_k)

@@ -149,6 +149,27 @@ int cmvae_reparam_logq_bwd(const float* logvar, const float* eps, const float* g
  * (GMVAE.h_a, omniglot/model.py:159-166).  A [64,64]; h [1]; grad [64,64] (may be NULL). */
 int cmvae_expm_trace(const float* A, float* h, float* grad, void* stream);
 
+/* ==== scalar tail of GMVAE.forward (omniglot/model.py:496-516) in two launches (backward: one).
+ * out = {kl, h_aug}:  kl = mean(log_q) - mean(log_p) - mean_rows(sum_d(-0.5 q_eps^2 + c)),  c = -0.5 log(2 pi);
+ *                     h_aug = h_lambda * h + 0.5 * h_c * h^2 + a_lambda * sum|A|.
+ * log_q [n1], log_p [n2], q_eps [rows, dim] (dim % 4 == 0), h: device scalar (cmvae_expm_trace), A [nA];
+ * part: [cmvae_elbo_tail_blocks()][4] scratch.
+ * Backward from g = {d kl, d h_aug} (device): d_log_q = g0/n1, d_log_p = -g0/n2, d_q_eps = g0 * q_eps / rows,
+ * dA = g1 * a_lambda * sign(A) (the |A| term only), dh = g1 * (h_lambda + h_c * h).                              */
+int cmvae_elbo_tail_blocks(void);
+int cmvae_elbo_tail_fwd(const float* log_q, int64_t n1, const float* log_p, int64_t n2, const float* q_eps,
+                        int64_t rows, int dim, const float* h, const float* A, int64_t nA, float h_lambda, float h_c,
+                        float a_lambda, float* part, float* out, void* stream);
+int cmvae_elbo_tail_bwd(const float* g, const float* h, const float* q_eps, int64_t rows, int dim, const float* A,
+                        int64_t nA, int64_t n1, int64_t n2, float h_lambda, float h_c, float a_lambda,
+                        float* d_log_q, float* d_log_p, float* d_q_eps, float* dA, float* dh, void* stream);
+/* Prior log-weights of the mixture term (omniglot/model.py:481-491; log(trace_k) sits in gaussian_log_prob's MEAN
+ * slot there, and here): logw[r] = log(pi[r]) + sum_d(-0.5 * (x[r][d] - lt)^2 + c), lt = log(trace[r]);
+ * x [rows, 64] = the causal layer's image of mu_k.  Backward: dx[r][d] = -g[r] * (x[r][d] - lt)  (pi and trace are
+ * EM outputs, constants).                                                                                       */
+int cmvae_prior_logw_fwd(const float* pi, const float* trace, const float* x, int rows, float* logw, void* stream);
+int cmvae_prior_logw_bwd(const float* trace, const float* x, const float* g, int rows, float* dx, void* stream);
+
 /* ==== dense contractions: fp32-MFMA gather-GEMM ========================================
  * Activations are row-major [pixels, C] (channels-last).  One geometry describes conv 3x3
  * (omniglot/module.py:14-29), each sub-pixel phase of the stride-2 transposed convs

@@ -219,6 +219,52 @@ def test_expm_trace(device, scale):
     assert abs(float(h.detach()) - float(h32)) <= 1e-4 * abs(float(href.detach())) + 64 * 6e-8 * 8
 
 
+@pytest.mark.parametrize('B,S,M,K', [(4, 300, 32, 20), (2, 7, 3, 5), (1, 1, 1, 2)])
+def test_elbo_tail_and_prior_logw(device, B, S, M, K):
+    """The fused scalar tail of forward (omniglot/model.py:481-491, 496-516) against the reference's own chain of
+    tensor expressions in float64, values and every gradient."""
+    from cmvae_amd import ops
+    g = torch.Generator().manual_seed(B * S + K)
+    D = 64
+    log_q = torch.randn(B, S, M, generator=g) * 3 - 80
+    log_p = torch.randn(B, S * M, generator=g) * 3 - 90
+    q_eps = torch.randn(B, S * M, D, generator=g)
+    A = torch.randn(D, D, generator=g) * 0.05
+    A[3, 4] = 0.0
+    pi = torch.softmax(torch.randn(B, K, generator=g), -1)
+    trace = torch.rand(B, K, generator=g) + 0.5
+    x = torch.randn(B, K, D, generator=g)
+    h_lambda, h_c, a_lambda = 0.7, 3.0, 0.01
+    c = -0.5 * np.log(2 * np.pi)
+
+    def leaves(dtype, dev):
+        return [t.to(dtype).to(dev).requires_grad_(True) for t in (log_q, log_p, q_eps, A, x)]
+
+    rq, rp, re, rA, rx = leaves(torch.float64, 'cpu')
+    hr = (torch.matrix_exp(rA * rA).diagonal().sum() - D)
+    kl_r = rq.mean() - rp.mean() - (-0.5 * re.pow(2) + c).sum(-1).mean()
+    ha_r = h_lambda * hr + 0.5 * h_c * hr * hr + a_lambda * rA.abs().sum()
+    lw_r = torch.log(pi.double()) + (-0.5 * (rx - torch.log(trace.double())[:, :, None]).pow(2) + c).sum(-1)
+    gw = torch.randn(B, K, generator=g)
+    (2.0 * kl_r + 0.5 * ha_r + (lw_r * gw.double()).sum()).backward()
+
+    dq, dp, de, dA, dx = leaves(torch.float32, device)
+    hd = ops.expm_trace(dA)
+    kl_d, ha_d = ops.elbo_tail(dq, dp, de, hd, dA, h_lambda, h_c, a_lambda)
+    lw_d = ops.prior_logw(pi.to(device), trace.to(device), dx)
+    (2.0 * kl_d + 0.5 * ha_d + (lw_d * gw.to(device)).sum()).backward()
+    assert abs(float(kl_d.detach()) - float(kl_r.detach())) < 1e-5 * abs(float(kl_r.detach()))
+    assert abs(float(ha_d.detach()) - float(ha_r.detach())) < 1e-5 * abs(float(ha_r.detach()))
+    assert rel_err(lw_d.detach(), lw_r.detach().float()) < 1e-6
+    for a, r in ((dq, rq), (dp, rp), (de, re), (dA, rA), (dx, rx)):
+        assert rel_err(a.grad, r.grad.float()) < 1e-5
+    # only one of the two outputs used: the other's gradient is taken as zero
+    dq2, dp2, de2, dA2, _ = leaves(torch.float32, device)
+    kl2, _ = ops.elbo_tail(dq2, dp2, de2, ops.expm_trace(dA2), dA2, h_lambda, h_c, a_lambda)
+    kl2.backward()
+    assert float(dA2.grad.abs().max()) == 0.0 and rel_err(de2.grad, re.grad.float() / 2.0) < 1e-5
+
+
 def test_missing_gpu_tensor_raises(device):
     from cmvae_amd import ops
     with pytest.raises(RuntimeError):

@@ -18,7 +18,9 @@ ACTS = {None: lambda v: v, 'relu': F.relu, 'elu': F.elu}
 
 @pytest.mark.parametrize('rows,in_f,out_f,act', [
     (300, 128, 256, 'elu'), (1000, 256, 256, 'relu'), (77, 64, 2048, 'elu'), (513, 2048, 64, None),
-    (1, 256, 128, None), (1200, 512, 512, 'relu'), (129, 64, 64, None)])
+    (1, 256, 128, None), (1200, 512, 512, 'relu'), (129, 64, 64, None),
+    # 64 -> many column blocks over >= 8192 rows: the weight-stationary kernel (ragged last row tile)
+    (8200, 64, 512, 'elu'), (9001, 64, 1024, None)])
 def test_linear_fwd_bwd(rows, in_f, out_f, act):
     from cmvae_amd.linear import linear
     g = torch.Generator().manual_seed(rows + in_f)
