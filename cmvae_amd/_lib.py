@@ -75,6 +75,10 @@ SIGNATURES = {
     'cmvae_colsum_reduce': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_bn_finalize': (c_int, [c_void_p, ctypes.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_bn_finalize_part': (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cmvae_bn_bwd_finalize_part': (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     'cmvae_bn_eval_fold': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
     'cmvae_rowpass_grid': (c_int, [c_int64]),

@@ -66,6 +66,81 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
     }
 }
 
+// The two finalize steps straight from the per-workgroup partials [nblk][128] (single process: no all-reduce sits
+// between the column sums and the finalize): one launch instead of colsum_reduce + finalize (+ the counter's add).
+// 64 column pairs x 16 row groups, fixed summation order; sums[] is left in LDS for the 64 finalizing threads.
+__device__ __forceinline__ void part_colsum_128(const float* __restrict__ part, int nblk, float* red, float* sums) {
+    // thread = (column pair, one of 16 row groups); twelve 8-byte loads in flight per thread: the kernel is pure latency
+    const int c2 = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const float2* p2 = reinterpret_cast<const float2*>(part) + c2;
+    float2 s0 = make_float2(0.f, 0.f), s1 = s0;
+    int b = g;
+    for (; b + 16 * 11 < nblk; b += 16 * 12) {
+        float2 v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = p2[(long)(b + 16 * i) * 64];
+#pragma unroll
+        for (int i = 0; i < 12; i += 2) { s0.x += v[i].x; s0.y += v[i].y; s1.x += v[i + 1].x; s1.y += v[i + 1].y; }
+    }
+    for (; b < nblk; b += 16) { const float2 v = p2[(long)b * 64]; s0.x += v.x; s0.y += v.y; }
+    red[g * 128 + 2 * c2] = s0.x + s1.x;
+    red[g * 128 + 2 * c2 + 1] = s0.y + s1.y;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r * 128 + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_part_kernel(const float* __restrict__ part, int nblk, float count,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps,
+                                                                float momentum, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var,
+                                                                long long* __restrict__ num_batches_tracked,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                float* __restrict__ mean_o,
+                                                                float* __restrict__ invstd_o) {
+    __shared__ float red[16 * 128];
+    __shared__ float sums[128];
+    part_colsum_128(part, nblk, red, sums);
+    const int c = threadIdx.x;
+    if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+    if (c >= C) return;
+    const float mean = sums[c] / count;
+    float var = sums[C + c] / count - mean * mean;
+    var = fmaxf(var, 0.f);
+    const float invstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    mean_o[c] = mean;
+    invstd_o[c] = invstd;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_part_kernel(const float* __restrict__ part, int nblk,
+                                                                    float count, float* __restrict__ c1,
+                                                                    float* __restrict__ c2,
+                                                                    float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta) {
+    __shared__ float red[16 * 128];
+    __shared__ float sums[128];
+    part_colsum_128(part, nblk, red, sums);
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    c1[c] = sums[c] / count;
+    c2[c] = sums[C + c] / count;
+    dbeta[c] = sums[c];
+    dgamma[c] = sums[C + c];
+}
+
 // eval mode: the fold from the running statistics (nn.BatchNorm2d.eval())
 __global__ void bn_eval_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -551,6 +626,29 @@ extern "C" int cmvae_bn_finalize(const float* sums, double count, const float* g
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, (float)count, gamma, beta,
                        eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
     return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int cmvae_bn_finalize_part(const float* part, int nblk, double count, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var,
+                                      int64_t* num_batches_tracked, float* scale, float* shift, float* mean,
+                                      float* invstd, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(part && gamma && beta && scale && shift && mean && invstd && nblk >= 1 && count >= 1,
+                  "cmvae_bn_finalize_part: bad arguments");
+    CMVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cmvae_bn_finalize_part: running stats go together");
+    hipLaunchKernelGGL(bn_finalize_part_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, nblk, (float)count,
+                       gamma, beta, eps, momentum, running_mean, running_var, (long long*)num_batches_tracked, scale,
+                       shift, mean, invstd);
+    return check_launch("bn_finalize_part_kernel");
+}
+
+extern "C" int cmvae_bn_bwd_finalize_part(const float* part, int nblk, double count, float* c1, float* c2,
+                                          float* dgamma, float* dbeta, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(part && c1 && c2 && dgamma && dbeta && nblk >= 1 && count >= 1, "cmvae_bn_bwd_finalize_part: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_part_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, nblk,
+                       (float)count, c1, c2, dgamma, dbeta);
+    return check_launch("bn_bwd_finalize_part_kernel");
 }
 
 extern "C" int cmvae_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean,

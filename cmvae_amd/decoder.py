@@ -57,6 +57,38 @@ def bn_finalize(sums, count, bn, training_update=True):
     return scale, shift, mean, invstd
 
 
+# CMVAE_FUSED_BN_FINALIZE=0: column sums and finalize as two launches also in a single process (A/B measurements)
+FUSED_BN_FINALIZE = os.environ.get('CMVAE_FUSED_BN_FINALIZE', '1') not in ('', '0')
+
+
+def bn_stats_finalize(part, count, bn):
+    """Training-mode fold (scale, shift, mean, invstd) from the conv GEMM's partial statistics [nblk,128]; count =
+    values per channel over ALL ranks.  One process: one launch (sums, finalize, running statistics and the batch
+    counter); several: column sums, all-reduce (collective C2), finalize."""
+    if _dist.world_size() > 1 or not FUSED_BN_FINALIZE or bn.momentum is None:
+        return bn_finalize(_global_sums(colsum(part)), count, bn)
+    dev = part.device
+    scale, shift, mean, invstd = (torch.empty(64, device=dev) for _ in range(4))
+    upd = bn.track_running_stats
+    check(lib.cmvae_bn_finalize_part(_p(part), part.shape[0], float(count), _p(bn.weight.detach()), _p(bn.bias.detach()),
+                                     bn.eps, bn.momentum, _p(bn.running_mean) if upd else None,
+                                     _p(bn.running_var) if upd else None, _p(bn.num_batches_tracked) if upd else None,
+                                     _p(scale), _p(shift), _p(mean), _p(invstd), _stream()), 'cmvae_bn_finalize_part')
+    return scale, shift, mean, invstd
+
+
+def bn_bwd_sums_finalize(part, count):
+    """(c1, c2, dgamma, dbeta) from partial BatchNorm-backward sums [nblk,128]; count = this rank's values per
+    channel."""
+    if _dist.world_size() > 1 or not FUSED_BN_FINALIZE:
+        return bn_bwd_finalize(colsum(part), count)
+    dev = part.device
+    c1, c2, dgamma, dbeta = (torch.empty(64, device=dev) for _ in range(4))
+    check(lib.cmvae_bn_bwd_finalize_part(_p(part), part.shape[0], float(count), _p(c1), _p(c2), _p(dgamma), _p(dbeta),
+                                         _stream()), 'cmvae_bn_bwd_finalize_part')
+    return c1, c2, dgamma, dbeta
+
+
 def bn_eval_fold(bn):
     scale, shift, invstd = (torch.empty(64, device=bn.weight.device) for _ in range(3))
     check(lib.cmvae_bn_eval_fold(_p(bn.weight.detach()), _p(bn.bias.detach()), _p(bn.running_mean), _p(bn.running_var),
@@ -91,7 +123,7 @@ def bn_relu_bwd_apply(d_a, y, fold, c1, c2, masked, out):
 
 
 def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
-    """x [n*Hi*Hi,64] (pre-fold) -> y [n*Ho*Ho,64]; returns (y, column sums {sum,sumsq} or None)."""
+    """x [n*Hi*Hi,64] (pre-fold) -> y [n*Ho*Ho,64]; returns (y, partial column sums {sum,sumsq} [nblk,128] or None)."""
     Ho = conv.convT_out(Hi, k)
     y = torch.empty(n * Ho * Ho, 64, device=x.device)
     wprep = weight.detach().permute(2, 3, 1, 0).contiguous()                 # [ky][kx][co][ci]: all k*k taps
@@ -100,7 +132,7 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
     if MULTI_PHASE:                      # all four phases in one launch
         part = conv.conv_gemm_multi([g for g, _ in phases], x, wprep, y, bias=bias.detach(), a_scale=sc, a_shift=sh,
                                     stats=want_stats)
-        return y, (colsum(part) if want_stats else None)
+        return y, (part if want_stats else None)
     part = None
     if want_stats:
         grids = [conv.gemm_grid(g.rows_total, 1) for g, _ in phases]
@@ -112,7 +144,7 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
         conv.conv_gemm(g, x, wprep, y, bias=bias.detach(), a_scale=sc, a_shift=sh, stats=st)
         if want_stats:
             off += grids[i]
-    return y, (colsum(part) if want_stats else None)
+    return y, (part if want_stats else None)
 
 
 # CMVAE_CONV_MULTI=0: one launch per sub-pixel phase of a transposed conv instead of one per layer (A/B measurements)
@@ -142,10 +174,10 @@ class _DecoderBCE(torch.autograd.Function):
         acts, folds = [h_rec.detach().reshape(n * 4, 64)], [None]
         world = _dist.world_size()
         for li, (k, Hi) in enumerate(_LAYERS):
-            y, sums = convT_forward(acts[-1], n, Hi, k, ws[li], bs[li], folds[-1], want_stats=training)
+            y, part = convT_forward(acts[-1], n, Hi, k, ws[li], bs[li], folds[-1], want_stats=training)
             if training:
                 count = y.shape[0] * world
-                fold = bn_finalize(_global_sums(sums), count, bns[li])
+                fold = bn_stats_finalize(part, count, bns[li])
             else:
                 fold = bn_eval_fold(bns[li])
             acts.append(y)
@@ -213,15 +245,17 @@ class _DecoderBCE(torch.autograd.Function):
             fused_sums = None
             if li > 0 and FUSED_BN_SUMS:
                 # the BatchNorm-backward sums of the layer below come out of the data gradient's epilogue
-                fused_sums = colsum(conv.conv_gemm_bnbwd(gd, dy, wtd, d_in, x_in, fold_in))
+                fused_sums = conv.conv_gemm_bnbwd(gd, dy, wtd, d_in, x_in, fold_in)      # partials [nblk,128]
             else:
                 conv.conv_gemm(gd, dy, wtd, d_in)
             dy_below = None
             if li > 0:
                 def bn_below():
-                    sums_b = fused_sums if fused_sums is not None else \
-                        bn_relu_bwd_sums(d_in, x_in, fold_in, masked=False)
-                    c1b, c2b, dg, dbe = bn_bwd_finalize(sums_b, x_in.shape[0])
+                    if fused_sums is not None:
+                        c1b, c2b, dg, dbe = bn_bwd_sums_finalize(fused_sums, x_in.shape[0])
+                    else:
+                        c1b, c2b, dg, dbe = bn_bwd_finalize(bn_relu_bwd_sums(d_in, x_in, fold_in, masked=False),
+                                                            x_in.shape[0])
                     grads_g[li - 1], grads_be[li - 1] = dg, dbe
                     return bn_relu_bwd_apply(d_in, x_in, fold_in, c1b, c2b, False, out=d_in)     # in place
                 if side is None:

@@ -11,8 +11,7 @@ import torch
 from . import conv
 from . import dist as _dist
 from ._lib import lib, check
-from .decoder import (colsum, bn_finalize, bn_eval_fold, bn_bwd_finalize, bn_relu_bwd_apply, _global_sums, _p,
-                      _stream)
+from .decoder import (colsum, bn_stats_finalize, bn_eval_fold, bn_bwd_sums_finalize, bn_relu_bwd_apply, _p, _stream)
 
 _SIZES = (28, 14, 7, 4)          # conv input sizes; pooled outputs are 14, 7, 4, 2
 TAPS = None                      # tests set this to a dict: receives the pre-BatchNorm outputs and folds of a forward
@@ -50,7 +49,7 @@ class _Encoder(torch.autograd.Function):
                 wt = ws[li].detach().permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous()      # [tap][co][ci]
                 part = conv.conv_gemm(conv.geom_conv3x3(n, H, H), a, wt, y, bias=bs[li].detach(), stats=training)
             if training:
-                fold = bn_finalize(_global_sums(colsum(part)), rows * world, bns[li])
+                fold = bn_stats_finalize(part, rows * world, bns[li])
             else:
                 fold = bn_eval_fold(bns[li])
             a = torch.empty(n * Ho * Ho, 64, device=dev)
@@ -82,7 +81,7 @@ class _Encoder(torch.autograd.Function):
             part = torch.empty(lib.cmvae_rowpass_grid(n * Ho * Ho), 128, device=dev)
             check(lib.cmvae_pool_bwd(_p(d), _p(y), *(_p(t) for t in fold), n, H, H, _p(dybn), _p(part), _stream()),
                   'cmvae_pool_bwd')
-            c1, c2, gg[li], gbe[li] = bn_bwd_finalize(colsum(part), rows)
+            c1, c2, gg[li], gbe[li] = bn_bwd_sums_finalize(part, rows)
             dy = bn_relu_bwd_apply(dybn, y, fold, c1, c2, True, out=dybn)
             if li > 0:
                 a_in = pooled[li - 1]

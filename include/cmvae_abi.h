@@ -311,6 +311,12 @@ int cmvae_colsum_reduce(const float* part, int nblk, int L, float* out, void* st
 int cmvae_bn_finalize(const float* sums, double count, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var,
                       float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* The same straight from the partials [nblk][128] of the conv GEMM's epilogue, in one launch (a single process has
+ * no all-reduce between the column sums and the finalize); num_batches_tracked (int64 on the device, or NULL) is
+ * incremented like nn.BatchNorm2d does.                                                                        */
+int cmvae_bn_finalize_part(const float* part, int nblk, double count, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float* scale, float* shift, float* mean, float* invstd, void* stream);
 /* model.eval(): the same fold from the running statistics (nn.BatchNorm2d in eval mode, used by
  * GMVAE.prediction, omniglot/model.py:520-585): scale = gamma*rsqrt(running_var+eps),
  * shift = beta - running_mean*scale, invstd.                                                   */
@@ -325,6 +331,9 @@ int cmvae_bn_relu_bwd_reduce(const float* d_a, const float* y, const float* scal
                              float* part, void* stream);
 int cmvae_bn_bwd_finalize(const float* sums_local, const float* sums_global, double count,
                           float* c1, float* c2, float* dgamma, float* dbeta, void* stream);
+/* ... from the partials [nblk][128] of one process (no all-reduce), in one launch.                              */
+int cmvae_bn_bwd_finalize_part(const float* part, int nblk, double count, float* c1, float* c2, float* dgamma,
+                               float* dbeta, void* stream);
 int cmvae_bn_relu_bwd_apply(const float* d_a, const float* y, const float* scale, const float* shift,
                             const float* mean, const float* invstd, const float* c1, const float* c2,
                             int64_t rows, int masked, float* dy, void* stream);

@@ -188,6 +188,33 @@ def test_dgrad_bn_sums_epilogue_weight_stationary_kernel(device):
     assert rel_err(s_got[:64], s_want[:64]) < 1e-5 and rel_err(s_got[64:], s_want[64:]) < 1e-5
 
 
+@pytest.mark.parametrize('nblk', [1, 7, 64, 512, 768])
+def test_bn_finalize_from_partials_equals_two_step_path(device, nblk):
+    """One launch (column sums + finalize + running statistics + batch counter) against colsum -> finalize; same
+    for the backward finalize.  The sums are taken in another order: equal to rounding."""
+    from cmvae_amd import decoder
+    g = torch.Generator().manual_seed(nblk)
+    count = 1000.0 * nblk
+    x = torch.randn(nblk, 64, generator=g).abs() * 1000 / nblk
+    part = torch.cat([x * 0.3, x * 0.3 * 0.3 + x], 1).to(device)          # {sum, sum of squares}: variance > 0
+    bns = []
+    for _ in range(2):
+        bn = torch.nn.BatchNorm2d(64).to(device)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(64, generator=torch.Generator().manual_seed(1)) + 0.5)
+            bn.bias.copy_(torch.randn(64, generator=torch.Generator().manual_seed(2)))
+        bns.append(bn)
+    want = decoder.bn_finalize(decoder.colsum(part), count, bns[0])
+    got = decoder.bn_stats_finalize(part, count, bns[1])
+    for a, b in zip(got, want):
+        assert rel_err(a, b) < 1e-5
+    assert rel_err(bns[1].running_mean, bns[0].running_mean) < 1e-5
+    assert rel_err(bns[1].running_var, bns[0].running_var) < 1e-5
+    assert int(bns[1].num_batches_tracked) == int(bns[0].num_batches_tracked) == 1
+    for a, b in zip(decoder.bn_bwd_sums_finalize(part, count), decoder.bn_bwd_finalize(decoder.colsum(part), count)):
+        assert rel_err(a, b) < 1e-5
+
+
 def test_multi_launch_rejects_what_it_cannot_run(device):
     """More than four taps or geometries, geometries over different tensors: an error, not a launch."""
     from cmvae_amd import conv

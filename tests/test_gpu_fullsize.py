@@ -37,7 +37,8 @@ def test_full_size_decoder_layer_image_slices(device):
     x = torch.empty(n * 49, 64, device=device).normal_(generator=torch.Generator(device=device).manual_seed(1))
     x[:3 * 49] = _nhwc(head).to(device)
     x[-2 * 49:] = _nhwc(tail).to(device)
-    y, sums = decoder.convT_forward(x, n, 7, 4, w.to(device), b.to(device), (sc.to(device), sh.to(device)), want_stats=True)
+    y, part = decoder.convT_forward(x, n, 7, 4, w.to(device), b.to(device), (sc.to(device), sh.to(device)), want_stats=True)
+    sums = decoder.colsum(part)
     for imgs, sl in ((head, slice(0, 3 * 196)), (tail, slice(n * 196 - 2 * 196, n * 196))):
         a = F.relu(imgs * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
         ref = F.conv_transpose2d(a, w, b, stride=2, padding=1)
