@@ -170,43 +170,78 @@ def pmc_traffic(select, largest=False):
     return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in sel) / n, os.path.basename(files[-1])
 
 
+def _template_args(kernel_name):
+    i, j = kernel_name.find('<'), kernel_name.rfind('>')
+    if i < 0 or j < i:
+        return []
+    return [a.strip() for a in kernel_name[i + 1:j].split(',')]
+
+
+def _is_conv_gemm(k):
+    """Kernel names of the conv / conv-transpose / data-gradient launches roofline_conv_gemm times:
+    conv_gemm_wstat_multi_kernel, conv_gemm_wstat_kernel<ACT = 0, ...> (an activation marks an nn.Linear launch),
+    conv_gemm_direct_kernel<ACT, LINEAR = false, ...>, conv_gemm_kernel."""
+    a = _template_args(k)
+    if k.startswith('conv_gemm_wstat_multi_kernel') or k.startswith('conv_gemm_kernel'):
+        return True
+    if k.startswith('conv_gemm_wstat_kernel'):
+        return len(a) > 0 and a[0] == '0'
+    if k.startswith('conv_gemm_direct_kernel'):
+        return len(a) > 1 and a[1] == 'false'
+    return False
+
+
+def _is_linear_gemm(k):
+    a = _template_args(k)
+    if k.startswith('conv_gemm_direct_kernel'):
+        return len(a) > 1 and a[1] == 'true'
+    if k.startswith('conv_gemm_wstat_kernel'):
+        return len(a) > 0 and a[0] != '0'
+    return False
+
+
 def pmc_traffic_conv_gemm():
-    """The conv launches of conv_gemm_wstat_kernel / conv_gemm_direct_kernel / conv_gemm_kernel (the last two with
-    template argument LINEAR = false): the launches roofline_conv_gemm times."""
-    return pmc_traffic(lambda k: k.startswith('conv_gemm_wstat_kernel') or
-                       (k.startswith(('conv_gemm_kernel', 'conv_gemm_direct_kernel')) and k.endswith('false>')))
+    return pmc_traffic(_is_conv_gemm)
 
 
 def roofline_conv_gemm(step_fn):
     """Dominant kernel family of the Omniglot step: the fp32-MFMA gather-GEMM (all decoder / encoder convs and their
-    data gradients).  Every launch of one extra, untimed training step is bracketed by HIP events on the launch
-    stream; achieved = sum of algorithmic FLOPs / sum of launch durations."""
+    data gradients; the four sub-pixel phases of a transposed conv are one launch).  Every launch of one extra,
+    untimed training step is bracketed by HIP events on the launch stream; achieved = sum of algorithmic FLOPs / sum
+    of launch durations."""
     import torch
     from cmvae_amd import conv
     rec = []
-    orig = conv.conv_gemm
+    origs = {n: getattr(conv, n) for n in ('conv_gemm', 'conv_gemm_multi', 'conv_gemm_bnbwd')}
 
-    def timed(g, A, Wt, out, bias=None, a_scale=None, a_shift=None, act=0, n_col_blocks=1, stats=False):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig(g, A, Wt, out, bias=bias, a_scale=a_scale, a_shift=a_shift, act=act, n_col_blocks=n_col_blocks,
-                 stats=stats)
-        e1.record()
-        rec.append((e0, e1, useful_flops(g, n_col_blocks)))
-        return r
+    def timed(name, flops_of):
+        orig = origs[name]
 
-    conv.conv_gemm = timed
+        def f(*args, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*args, **kw)
+            e1.record()
+            rec.append((e0, e1, flops_of(*args, **kw)))
+            return r
+        return f
+
+    conv.conv_gemm = timed('conv_gemm', lambda g, *a, **kw: useful_flops(g, kw.get('n_col_blocks', 1)))
+    conv.conv_gemm_multi = timed('conv_gemm_multi', lambda gs, *a, **kw: sum(useful_flops(g, 1) for g in gs))
+    conv.conv_gemm_bnbwd = timed('conv_gemm_bnbwd', lambda g, *a, **kw: useful_flops(g, 1))
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
-        conv.conv_gemm = orig
+        for n, f in origs.items():
+            setattr(conv, n, f)
     total_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
     total_flops = sum(f for _, _, f in rec)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
     traffic, src = pmc_traffic_conv_gemm()
-    return {'kernel': 'conv_gemm_wstat_kernel + conv_gemm_direct_kernel (conv / conv-transpose / data-gradient launches)',
+    return {'kernel': 'conv_gemm_wstat(_multi)_kernel + conv_gemm_direct_kernel (conv / conv-transpose / data-gradient '
+                      'launches)',
             'bound': 'mfma', 'achieved': round(achieved, 2),
             'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': src,
@@ -242,8 +277,7 @@ def roofline_linear(step_fn):
     total_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
     total_flops = sum(f for _, _, f in rec)
     achieved = total_flops / (total_ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic(lambda k: k.startswith(('conv_gemm_kernel', 'conv_gemm_direct_kernel')) and
-                               k.endswith('true>'))
+    traffic, src = pmc_traffic(_is_linear_gemm)
     return {'kernel': 'conv_gemm_direct_kernel<LINEAR> (nn.Linear forward launches)', 'bound': 'mfma',
             'achieved': round(achieved, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,

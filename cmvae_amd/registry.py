@@ -221,6 +221,77 @@ def _adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, we
                               eps, weight_decay, ops._stream()), 'cmvae_adam_step')
 
 
+# ----------------------------------------------------------------------------- scalar tail of forward
+_d.define('prior_logw_fwd(Tensor pi, Tensor trace, Tensor x) -> Tensor')
+_d.define('prior_logw_bwd(Tensor trace, Tensor x, Tensor g) -> Tensor')
+_d.define('elbo_tail_fwd(Tensor log_q, Tensor log_p, Tensor q_eps, Tensor h, Tensor A, float h_lambda, float h_c, '
+          'float a_lambda) -> Tensor')
+_d.define('elbo_tail_bwd(Tensor g, Tensor h, Tensor q_eps, Tensor A, int n1, int n2, float h_lambda, float h_c, '
+          'float a_lambda) -> (Tensor, Tensor, Tensor, Tensor, Tensor)')
+
+
+def _gpu32(t, name):
+    t = t.contiguous()
+    linear._need(t, name)
+    return t
+
+
+def _prior_logw_fwd(pi, trace, x):
+    pi, trace, x = (_gpu32(t, n) for t, n in ((pi, 'pi'), (trace, 'trace'), (x, 'x')))
+    if x.shape[-1] != 64 or pi.numel() * 64 != x.numel() or trace.numel() != pi.numel():
+        raise RuntimeError('cmvae_amd: prior_logw takes pi, trace [B,K] and x [B,K,64]')
+    logw = torch.empty_like(pi)
+    check(lib.cmvae_prior_logw_fwd(_p(pi), _p(trace), _p(x), pi.numel(), _p(logw), ops._stream()),
+          'cmvae_prior_logw_fwd')
+    return logw
+
+
+def _prior_logw_bwd(trace, x, g):
+    trace, x, g = (_gpu32(t, n) for t, n in ((trace, 'trace'), (x, 'x'), (g, 'g')))
+    if x.shape[-1] != 64 or trace.numel() * 64 != x.numel() or g.numel() != trace.numel():
+        raise RuntimeError('cmvae_amd: prior_logw_bwd takes trace, g [B,K] and x [B,K,64]')
+    dx = torch.empty_like(x)
+    check(lib.cmvae_prior_logw_bwd(_p(trace), _p(x), _p(g), trace.numel(), _p(dx), ops._stream()),
+          'cmvae_prior_logw_bwd')
+    return dx
+
+
+def _tail_args(q_eps, h, A):
+    q_eps, A = _gpu32(q_eps, 'q_eps'), _gpu32(A, 'A')
+    h1 = _gpu32(h.reshape(1), 'h')
+    dim = q_eps.shape[-1]
+    if q_eps.numel() == 0 or dim % 4:
+        raise RuntimeError('cmvae_amd: elbo_tail takes a non-empty q_eps [.., D] with D a multiple of 4')
+    return q_eps, h1, A, q_eps.numel() // dim, dim
+
+
+def _elbo_tail_fwd(log_q, log_p, q_eps, h, A, h_lambda, h_c, a_lambda):
+    log_q, log_p = _gpu32(log_q, 'log_q'), _gpu32(log_p, 'log_p')
+    q_eps, h1, A, rows, dim = _tail_args(q_eps, h, A)
+    if log_q.numel() == 0 or log_p.numel() == 0:
+        raise RuntimeError('cmvae_amd: elbo_tail takes non-empty log_q / log_p')
+    part = torch.empty(lib.cmvae_elbo_tail_blocks(), 4, device=q_eps.device, dtype=torch.float32)
+    out = torch.empty(2, device=q_eps.device, dtype=torch.float32)
+    check(lib.cmvae_elbo_tail_fwd(_p(log_q), log_q.numel(), _p(log_p), log_p.numel(), _p(q_eps), rows, dim, _p(h1),
+                                  _p(A), A.numel(), h_lambda, h_c, a_lambda, _p(part), _p(out), ops._stream()),
+          'cmvae_elbo_tail_fwd')
+    return out
+
+
+def _elbo_tail_bwd(g, h, q_eps, A, n1, n2, h_lambda, h_c, a_lambda):
+    g = _gpu32(g, 'g')
+    q_eps, h1, A, rows, dim = _tail_args(q_eps, h, A)
+    if g.numel() != 2 or n1 < 1 or n2 < 1:
+        raise RuntimeError('cmvae_amd: elbo_tail_bwd takes g = {d kl, d h_aug} and the element counts of log_q / log_p')
+    dev = q_eps.device
+    d_q, d_p = torch.empty(n1, device=dev), torch.empty(n2, device=dev)
+    d_e, dA, dh = torch.empty_like(q_eps), torch.empty_like(A), torch.empty(1, device=dev)
+    check(lib.cmvae_elbo_tail_bwd(_p(g), _p(h1), _p(q_eps), rows, dim, _p(A), A.numel(), n1, n2, h_lambda, h_c,
+                                  a_lambda, _p(d_q), _p(d_p), _p(d_e), _p(dA), _p(dh), ops._stream()),
+          'cmvae_elbo_tail_bwd')
+    return d_q, d_p, d_e, dA, dh
+
+
 # ----------------------------------------------------------------------------- gather-GEMM family
 _d.define('conv_gemm(int[] geom, Tensor A, Tensor Wt, Tensor(a!) out, Tensor? bias, Tensor? a_scale, Tensor? a_shift, '
           'int act, int n_col_blocks, bool stats) -> Tensor')
@@ -292,7 +363,9 @@ for _name, _fn in (('unsup_prior', _unsup_prior), ('semi_prior', _semi_prior), (
                    ('attention_bwd', _attention_bwd), ('adam_step', _adam_step), ('conv_gemm', _conv_gemm),
                    ('attention_qkv_fwd', _attention_qkv_fwd), ('attention_qkv_bwd', _attention_qkv_bwd),
                    ('conv_wgrad', _conv_wgrad), ('conv_gemm_multi', _conv_gemm_multi),
-                   ('conv_gemm_bnbwd', _conv_gemm_bnbwd),
+                   ('conv_gemm_bnbwd', _conv_gemm_bnbwd), ('prior_logw_fwd', _prior_logw_fwd),
+                   ('prior_logw_bwd', _prior_logw_bwd), ('elbo_tail_fwd', _elbo_tail_fwd),
+                   ('elbo_tail_bwd', _elbo_tail_bwd),
                    ('conv_wgrad_multi', _conv_wgrad_multi)):
     _d.impl(_name, _fn, 'CUDA')
 
@@ -300,7 +373,7 @@ REGISTERED = ('mixture_loglik_fwd', 'mixture_loglik_bwd', 'reparam_logq_fwd', 'r
               'unsup_prior', 'semi_prior', 'posterior_argmax', 'causal_rows', 'gram_inverse', 'center_rows',
               'linear_fwd', 'linear_bwd', 'linear_mse_fwd', 'mse_act_bwd', 'act_bwd', 'attention_fwd', 'attention_bwd',
               'adam_step', 'conv_gemm', 'conv_wgrad', 'conv_gemm_multi', 'conv_wgrad_multi', 'attention_qkv_fwd',
-              'attention_qkv_bwd', 'conv_gemm_bnbwd')
+              'attention_qkv_bwd', 'conv_gemm_bnbwd', 'prior_logw_fwd', 'prior_logw_bwd', 'elbo_tail_fwd', 'elbo_tail_bwd')
 
 
 # ----------------------------------------------------------------------------- whole encoder / decoder

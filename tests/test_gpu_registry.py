@@ -44,6 +44,41 @@ def test_em_and_prediction_ops_equal_the_host_functions(device):
         O.unsup_prior(z, idx, [A, A], 4, False, 1.0)
 
 
+def test_scalar_tail_ops_equal_the_host_functions(device):
+    from cmvae_amd import ops
+    O = torch.ops.cmvae_amd
+    g = torch.Generator().manual_seed(11)
+    log_q = (torch.randn(2, 7, 3, generator=g) - 50).to(device)
+    log_p = (torch.randn(2, 21, generator=g) - 60).to(device)
+    q_eps = torch.randn(2, 21, 64, generator=g).to(device)
+    A = (torch.randn(64, 64, generator=g) * 0.05).to(device)
+    pi = torch.softmax(torch.randn(2, 5, generator=g), -1).to(device)
+    trace = (torch.rand(2, 5, generator=g) + 0.5).to(device)
+    x = torch.randn(2, 5, 64, generator=g).to(device)
+    h = ops.expm_trace(A)
+    kl, ha = ops.elbo_tail(log_q, log_p, q_eps, h, A, 0.3, 2.0, 0.01)
+    out = O.elbo_tail_fwd(log_q, log_p, q_eps, h, A, 0.3, 2.0, 0.01)
+    assert torch.equal(out, torch.stack([kl, ha]))
+    gq = torch.tensor([1.5, -0.5], device=device)
+    d_q, d_p, d_e, dA, dh = O.elbo_tail_bwd(gq, h, q_eps, A, log_q.numel(), log_p.numel(), 0.3, 2.0, 0.01)
+    leaves = [t.clone().requires_grad_(True) for t in (log_q, log_p, q_eps, A)]
+    hh = h.clone().requires_grad_(True)
+    kl2, ha2 = ops.elbo_tail(leaves[0], leaves[1], leaves[2], hh, leaves[3], 0.3, 2.0, 0.01)
+    (1.5 * kl2 - 0.5 * ha2).backward()
+    assert torch.equal(d_q.view_as(log_q), leaves[0].grad) and torch.equal(d_p.view_as(log_p), leaves[1].grad)
+    assert torch.equal(d_e, leaves[2].grad) and torch.equal(dA, leaves[3].grad) and torch.equal(dh.reshape(()), hh.grad)
+    lw = O.prior_logw_fwd(pi, trace, x)
+    assert torch.equal(lw, ops.prior_logw(pi, trace, x))
+    gw = torch.randn(2, 5, generator=g).to(device)
+    xr = x.clone().requires_grad_(True)
+    (ops.prior_logw(pi, trace, xr) * gw).sum().backward()
+    assert torch.equal(O.prior_logw_bwd(trace, x, gw), xr.grad)
+    with pytest.raises(RuntimeError):
+        O.prior_logw_fwd(pi, trace, x[:, :, :32])
+    with pytest.raises(RuntimeError):
+        O.elbo_tail_bwd(gq[:1], h, q_eps, A, 1, 1, 0.3, 2.0, 0.01)
+
+
 def test_linear_attention_adam_ops(device):
     from cmvae_amd.linear import linear, attention
     O = torch.ops.cmvae_amd
