@@ -623,7 +623,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_direct_kernel(ConvGeom g, co
 constexpr int WSTAT_TAPS4 = 4, WSTAT_TAPS8 = 9;
 // bid / nblk: the workgroup's index among the workgroups that share this geometry (a launch may run several
 // geometries side by side: conv_gemm_wstat_multi_kernel); stats_bid / stats_nblk: its index in the whole launch.
-template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false>
+// ACCUM: the launch adds to what `out` already holds (the second half of a tap set too large for LDS).
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false>
 __device__ __forceinline__ void wstat_body(
     const ConvGeom& g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
@@ -771,8 +772,14 @@ __device__ __forceinline__ void wstat_body(
                 const int opv[4] = {ops.x, ops.y, ops.z, ops.w};
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
-                    const floatx2 v0 = floatx2{acc0[4 * rq + r], acc0[4 * rq + r + 1]} + bb0;
-                    const floatx2 v1 = floatx2{acc1[4 * rq + r], acc1[4 * rq + r + 1]} + bb1;
+                    floatx2 v0 = floatx2{acc0[4 * rq + r], acc0[4 * rq + r + 1]} + bb0;
+                    floatx2 v1 = floatx2{acc1[4 * rq + r], acc1[4 * rq + r + 1]} + bb1;
+                    if (ACCUM) {
+                        const float* p0 = (const float*)(ob + (__umul24((unsigned)opv[r], pitch_b) + col_b));
+                        const float* p1 = (const float*)(ob + (__umul24((unsigned)opv[r + 1], pitch_b) + col_b));
+                        v0 += floatx2{p0[0], p1[0]};
+                        v1 += floatx2{p0[32], p1[32]};
+                    }
                     if (BNB) {
                         const float* x0 = (const float*)(xb + (__umul24((unsigned)opv[r], pitch_b) + col_b));
                         const float* x1 = (const float*)(xb + (__umul24((unsigned)opv[r + 1], pitch_b) + col_b));
@@ -808,7 +815,8 @@ __device__ __forceinline__ void wstat_body(
                 const int op = op_w[(reg & 3) + 8 * (reg >> 2) + 4 * h];
                 if (op >= 0) {
                     float* o = out + (long)op * g.o_pitch + nb * 64;
-                    const float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
+                    float v0 = acc0[reg] + b0, v1 = acc1[reg] + b1;
+                    if (ACCUM) { v0 += o[i]; v1 += o[32 + i]; }
                     if (BNB) {
                         const float* xr = bnb.x + (long)op * g.o_pitch + nb * 64;
                         const float x0 = xr[i], x1 = xr[32 + i];
@@ -858,12 +866,12 @@ __device__ __forceinline__ void wstat_body(
     }
 }
 
-template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false>
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kernel(
     ConvGeom g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
     float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps, BnBwd bnb = BnBwd{}) {
-    wstat_body<ACT, HAS_T, NW, PM, BNB>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps,
+    wstat_body<ACT, HAS_T, NW, PM, BNB, ACCUM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps,
                                         (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.x,
                                         (int)gridDim.x, bnb);
 }
@@ -888,13 +896,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_wstat_multi_kernel(
                                   b - p.begin[ph], p.begin[ph + 1] - p.begin[ph], 0, b, (int)gridDim.x);
 }
 
-template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false>
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false>
 static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, const float* bias, const float* a_scale,
                         const float* a_shift, float* out, float* stats_part, int stats_rows, int n_col_blocks,
                         int tap0, int ntaps, hipStream_t st, BnBwd bnb = BnBwd{}) {
     const size_t lds = (size_t)ntaps * 64 * LDA * sizeof(float) + 2 * NW * 32 * sizeof(int) + NW * 128 * sizeof(float);
     static const bool opted = [] {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB>,
+        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         return true;
@@ -902,14 +910,14 @@ static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, cons
     (void)opted;
     const int ntiles = (g.rows_total + 32 * NW - 1) / (32 * NW);
     // resident workgroups: two (NW = 4) or one (NW = 8) per CU
-    static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB>, 64 * NW,
+    static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM>, 64 * NW,
                                            (NW == 4 ? 2 : 1) * compute_units());
     // (nn.Linear launches: the column blocks share the resident workgroups)
     int most = (NW == 4 ? 2 : 1) * compute_units() / (n_col_blocks > 0 ? n_col_blocks : 1);
     if (most < 1) most = 1;
     const int cap_use = cap < most ? cap : most;
     const dim3 grid(ntiles < cap_use ? ntiles : cap_use, n_col_blocks);
-    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
+    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
                        a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps, bnb);
     return check_launch("conv_gemm_wstat_kernel");
 }
@@ -1598,6 +1606,26 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     return check_launch("conv_gemm_kernel");
 }
 
+// CMVAE_SPLIT_DGRAD=0 keeps the 16-tap data gradients on the direct kernel (A/B measurements)
+static bool split_dgrad_enabled() {
+    static const bool on = [] { const char* e = getenv("CMVAE_SPLIT_DGRAD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// every grid position keeps at least one in-image tap in taps [0, n/2) and in [n/2, n)
+static bool halves_nonempty(const ConvGeom& g) {
+    const int h0 = g.ntaps / 2;
+    for (int y = 0; y < g.Hg; ++y)
+        for (int x = 0; x < g.Wg; ++x) {
+            bool a = false, b = false;
+            for (int t = 0; t < g.ntaps; ++t) {
+                const bool in = (unsigned)(y * g.sy + g.dy[t]) < (unsigned)g.Hi && (unsigned)(x * g.sx + g.dx[t]) < (unsigned)g.Wi;
+                if (in) (t < h0 ? a : b) = true;
+            }
+            if (!a || !b) return false;
+        }
+    return true;
+}
+
 extern "C" int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A, const float* Wt, float* out,
                                      const float* x, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, float* sums_part, void* stream) {
@@ -1617,6 +1645,15 @@ extern "C" int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A
     const float* none = nullptr;
     if (g.pm_nimg > 0 && g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256)
         return launch_wstat<0, false, 8, true, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, 0, g.ntaps, st, bnb);
+    // 10 .. 16 taps (the 4x4 transposed convs' data gradients): two weight-stationary launches of half the taps each,
+    // the second adding to the first one's output — the read-modify-write of the output (0.5 GB at layer 3) costs less
+    // than the direct kernel's two barriers and weight staging per tap.  Every tile must keep a tap in both halves.
+    if (g.pm_nimg > 0 && g.ntaps > WSTAT_TAPS8 && g.ntaps <= 16 && g.rows_total >= 3 * 256 * 256 && split_dgrad_enabled() &&
+        halves_nonempty(g)) {
+        const int h0 = g.ntaps / 2;
+        if (int e = launch_wstat<0, false, 8, true, false, false>(g, A, Wt, none, none, none, out, nullptr, 0, 1, 0, h0, st)) return e;
+        return launch_wstat<0, false, 8, true, true, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, h0, g.ntaps - h0, st, bnb);
+    }
     const dim3 grid(gx, 1);
     if (g.pm_nimg > 0)
         hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, true, true>), grid, dim3(256), 0, st, g, A, Wt, none, out, sums_part, none, 1, 0, bnb);

@@ -215,6 +215,38 @@ def test_bn_finalize_from_partials_equals_two_step_path(device, nblk):
         assert rel_err(a, b) < 1e-5
 
 
+def test_dgrad_bn_sums_sixteen_taps_in_two_accumulating_launches(device):
+    """Layer-3 shape of the training step (16-tap data gradient over >= 196608 rows): two weight-stationary launches
+    of eight taps, the second adding to the first one's output.  The two half sums are added in another order than
+    the single accumulator chain of the direct kernel: equal to rounding; the sums equal the separate reduction."""
+    from cmvae_amd import conv, decoder
+    n, Hi, k = 4112, 7, 4
+    Ho = conv.convT_out(Hi, k)
+    g = torch.Generator().manual_seed(9)
+    gy = torch.randn(n * Ho * Ho, 64, generator=g).to(device)
+    x = torch.randn(n * Hi * Hi, 64, generator=g).to(device)
+    wtd = (torch.randn(k, k, 64, 64, generator=g) * 0.1).to(device)
+    fold = tuple(t.to(device) for t in (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3,
+                                        torch.randn(64, generator=g) * 0.2, torch.rand(64, generator=g) + 0.5))
+    gd, _ = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=True)
+    want = torch.empty(n * Hi * Hi, 64, device=device)
+    conv.conv_gemm(gd, gy, wtd, want)                       # direct kernel, one chain over the 16 taps
+    got = torch.full_like(want, float('nan'))
+    part = conv.conv_gemm_bnbwd(gd, gy, wtd, got, x, fold)
+    assert rel_err(got, want) < 1e-6
+    assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
+    s_want = decoder.bn_relu_bwd_sums(got, x, fold, masked=False)
+    s_got = decoder.colsum(part)
+    assert rel_err(s_got[:64], s_want[:64]) < 1e-5 and rel_err(s_got[64:], s_want[64:]) < 1e-5
+    # fp64 reference on a few images
+    sel = torch.arange(0, n, 517)
+    gy4 = gy.view(n, Ho, Ho, 64)[sel].permute(0, 3, 1, 2).double().cpu()   # (pixel-major is the launch's row ORDER only)
+    w = wtd.permute(2, 3, 0, 1).double().cpu()                                          # [ci][co][ky][kx]
+    ref = F.conv2d(gy4, w, None, 2, 1)                                                  # dgrad of convT(k, 2, 1)
+    mine = got.view(n, Hi, Hi, 64)[sel].permute(0, 3, 1, 2).double().cpu()
+    assert rel_err(mine, ref) < 1e-5
+
+
 def test_multi_launch_rejects_what_it_cannot_run(device):
     """More than four taps or geometries, geometries over different tensors: an error, not a launch."""
     from cmvae_amd import conv
