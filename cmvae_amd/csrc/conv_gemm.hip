@@ -936,6 +936,7 @@ static int dispatch_wstat(const ConvGeom& g, const float* A, const float* Wt, co
     // (below three 256-row tiles per workgroup its single round of 256 workgroups is mostly tail: the few-shot
     // evaluation's second encoder layer, 78400 rows = 306 tiles, ran 125 us here against the direct kernel's 128-row
     // tiles on three workgroups per CU)
+    // (a launch of at most one 256-row tile per CU — a single round again — was measured too: no gain, 13.07 vs 13.07 ms)
     if (g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256)
         return launch_wstat<ACT, HAS_T, 8, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows,
                                                n_col_blocks, 0, g.ntaps, st);
@@ -1607,9 +1608,13 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
 }
 
 // CMVAE_SPLIT_DGRAD=0 keeps the 16-tap data gradients on the direct kernel (A/B measurements)
-static bool split_dgrad_enabled() {
-    static const bool on = [] { const char* e = getenv("CMVAE_SPLIT_DGRAD"); return !(e && e[0] == '0'); }();
-    return on;
+static int split_dgrad_min_rows() {
+    static const int v = [] {
+        const char* e = getenv("CMVAE_SPLIT_DGRAD");
+        const int r = e ? atoi(e) : 1;
+        return r == 0 ? 0x7fffffff : (r == 1 ? 3 * 256 * 256 : r);      // 0: off, 1: default, else: the threshold
+    }();
+    return v;
 }
 // every grid position keeps at least one in-image tap in taps [0, n/2) and in [n/2, n)
 static bool halves_nonempty(const ConvGeom& g) {
@@ -1648,7 +1653,7 @@ extern "C" int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A
     // 10 .. 16 taps (the 4x4 transposed convs' data gradients): two weight-stationary launches of half the taps each,
     // the second adding to the first one's output — the read-modify-write of the output (0.5 GB at layer 3) costs less
     // than the direct kernel's two barriers and weight staging per tap.  Every tile must keep a tap in both halves.
-    if (g.pm_nimg > 0 && g.ntaps > WSTAT_TAPS8 && g.ntaps <= 16 && g.rows_total >= 3 * 256 * 256 && split_dgrad_enabled() &&
+    if (g.pm_nimg > 0 && g.ntaps > WSTAT_TAPS8 && g.ntaps <= 16 && g.rows_total >= split_dgrad_min_rows() &&
         halves_nonempty(g)) {
         const int h0 = g.ntaps / 2;
         if (int e = launch_wstat<0, false, 8, true, false, false>(g, A, Wt, none, none, none, out, nullptr, 0, 1, 0, h0, st)) return e;
