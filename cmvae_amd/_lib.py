@@ -94,6 +94,10 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p]),
     'cmvae_dec_out_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    'cmvae_dec_out_bwd_sums_partial_len': (c_int, []),
+    'cmvae_dec_out_bwd_sums_grid': (c_int, [c_int]),
+    'cmvae_dec_out_bwd_sums': (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p]),
     'cmvae_dec_out_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cmvae_enc_conv1_pool_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,

@@ -594,6 +594,177 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 3) void dec_out_bwd_kernel(con
     if (tid == 0) pb[1024 + 128] = (dbred[0] + dbred[1]) + (dbred[2] + dbred[3]);
 }
 
+// ------------------------------------------------------------------ the sums pass by linearity
+// Everything dec_out_bwd_kernel<0> hands on is linear in dlogit, so it follows from TWO contractions over the pixels,
+//   R[ci][tap] = sum_pix m * xhat * D[pix][tap],   P[ci][tap] = sum_pix m * D[pix][tap]       (m = relu mask of bn3(y3)):
+//   dW4[ci][tap] = gamma R + beta P   (a3 = m (gamma xhat + beta); gamma = scale/invstd, beta = shift + scale*mean)
+//   sum dybn3[ci] = sum_tap w4[ci][tap] P[ci][tap],   sum dybn3*xhat[ci] = sum_tap w4[ci][tap] R[ci][tap].
+// The gradient tile G = D . w4^T, its trip through LDS and the per-row mask / sum arithmetic of the general kernel
+// (about 100 VALU instructions per 16-pixel block, which on gfx950 take their cycles out of the MFMA time) are gone:
+// per block 12 VALU instructions per row, two staged operands (m*xhat, m) and 32 MFMAs.
+// part[blk] = { R[64][16], P[64][16], db4 };  dec_out_sums_finalize_kernel turns the column sums into the layout of
+// dec_out_bwd_kernel<0>'s partials { dW4, sum dybn3, sum dybn3*xhat, db4 }.
+constexpr int DEC_LIN_L = 2 * 64 * 16 + 1;
+
+__global__ __launch_bounds__(256, 3) void dec_out_bwd_lin_kernel(const float* __restrict__ y3,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ p_in,
+                                                                 const float* __restrict__ target, int M, int nimg,
+                                                                 const float* __restrict__ g_dev, float gmul,
+                                                                 float* __restrict__ part) {
+    const float gscale = gmul * (g_dev ? g_dev[0] : 1.f);
+    constexpr int PL = HO + 2;                     // zero-padded border: taps never branch
+    __shared__ float dl[2][PL * PL];
+    __shared__ __align__(16) float xst[4][16 * SP];      // m * xhat, per wave
+    __shared__ __align__(16) float mst[4][16 * SP];      // m
+    __shared__ float dbred[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const float4 sc = reinterpret_cast<const float4*>(scale)[i], sh = reinterpret_cast<const float4*>(shift)[i];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[i], is = reinterpret_cast<const float4*>(invstd)[i];
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    const floatx2 scl = {sc.x, sc.y}, sch = {sc.z, sc.w}, shl = {sh.x, sh.y}, shh = {sh.z, sh.w};
+    const floatx2 isl = {is.x, is.y}, ish = {is.z, is.w};
+    const floatx2 nml = {-mu.x * is.x, -mu.y * is.y}, nmh = {-mu.z * is.z, -mu.w * is.w};
+    floatx4 dr[4], dp[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) { dr[cb] = floatx4{0.f, 0.f, 0.f, 0.f}; dp[cb] = dr[cb]; }
+    float dbs = 0.f;
+    for (int e = tid; e < 2 * PL * PL; e += 256) (&dl[0][0])[e] = 0.f;
+    __syncthreads();
+    int buf = 0;
+    float* xw = xst[w];
+    float* mw = mst[w];
+    constexpr int NPT = (NPIX_O + 255) / 256;
+    float pp[NPT], tt[NPT];
+    float4 vv[4];
+    auto fetch_pt = [&](int img) {
+        const float* tg = target + (long)(img / M) * NPIX_O;
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int o = tid + 256 * k, oo = o < NPIX_O ? o : 0;
+            pp[k] = p_in[(long)img * NPIX_O + oo];
+            tt[k] = tg[oo];
+        }
+    };
+    auto fetch_rows = [&](int img, int rbk) {
+        const float* yi = y3 + (long)img * NPIX_I * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int px = 16 * rbk + g + 4 * j;
+            vv[j] = *reinterpret_cast<const float4*>(yi + (px < NPIX_I ? px : NPIX_I - 1) * C + 4 * i);
+        }
+    };
+    if ((int)blockIdx.x < nimg) {
+        fetch_pt(blockIdx.x);
+        fetch_rows(blockIdx.x, w);
+    }
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x, buf ^= 1) {
+        float* dlb = dl[buf];
+        const bool more = img + (int)gridDim.x < nimg;
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int o = tid + 256 * k;
+            const float p = pp[k], x = tt[k];
+            const float pq = p * (1.f - p);
+            const float d = gscale * (p - x) * (pq >= 1e-12f ? 1.f : pq * 1e12f);     // as dec_out_bwd_kernel
+            const int oy = o / HO;
+            if (o < NPIX_O) {
+                dlb[(oy + 1) * PL + (o - oy * HO) + 1] = d;
+                dbs += d;
+            }
+        }
+        if (more) fetch_pt(img + gridDim.x);
+        __syncthreads();          // the only block barrier per image (dl is double-buffered)
+        for (int rbk = w; rbk < RB; rbk += 4) {
+            // ---- rows: m * xhat and m, staged for the contraction over the pixels
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = g + 4 * j, px = 16 * rbk + rr;
+                const bool ok = px < NPIX_I;
+                const float4 v = vv[j];
+                const floatx2 vl = {v.x, v.y}, vh = {v.z, v.w};
+                const floatx2 al = __builtin_elementwise_fma(vl, scl, shl), ah = __builtin_elementwise_fma(vh, sch, shh);
+                const floatx2 xl = __builtin_elementwise_fma(vl, isl, nml), xh = __builtin_elementwise_fma(vh, ish, nmh);
+                float4 m;
+                m.x = (ok && al.x > 0.f) ? 1.f : 0.f; m.y = (ok && al.y > 0.f) ? 1.f : 0.f;
+                m.z = (ok && ah.x > 0.f) ? 1.f : 0.f; m.w = (ok && ah.y > 0.f) ? 1.f : 0.f;
+                const floatx2 rl = floatx2{m.x, m.y} * xl, rh = floatx2{m.z, m.w} * xh;
+                *reinterpret_cast<float4*>(&xw[rr * SP + 4 * i]) = make_float4(rl.x, rl.y, rh.x, rh.y);
+                *reinterpret_cast<float4*>(&mw[rr * SP + 4 * i]) = m;
+            }
+            if (rbk + 4 < RB) fetch_rows(img, rbk + 4);
+            else if (more) fetch_rows(img + gridDim.x, w);
+            // ---- R += (m xhat)^T . D,  P += m^T . D   (contraction over the 16 pixels: 4 k-steps of 4)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int px = 16 * rbk + 4 * s4 + g;
+                const bool ok = px < NPIX_I;
+                const int iy = px / HI, ix = px - iy * HI;
+                float b = dlb[ok ? (2 * iy + (i >> 2)) * PL + 2 * ix + (i & 3) : 0];   // tap i = ky*4 + kx
+                b = ok ? b : 0.f;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    dr[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[(4 * s4 + g) * SP + 16 * cb + i], b, dr[cb], 0, 0, 0);
+                    dp[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(mw[(4 * s4 + g) * SP + 16 * cb + i], b, dp[cb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- block partials (fixed order): R, P, db4
+    __syncthreads();
+    float* red = &xst[0][0];                       // 4 waves x 1024 floats = 16 KB <= sizeof(xst)
+    float* red2 = &mst[0][0];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            red[w * 1024 + (16 * cb + 4 * g + reg) * 16 + i] = dr[cb][reg];
+            red2[w * 1024 + (16 * cb + 4 * g + reg) * 16 + i] = dp[cb][reg];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dbs += __shfl_xor(dbs, o);
+    if (lane == 0) dbred[w] = dbs;
+    __syncthreads();
+    float* pb = part + (long)blockIdx.x * DEC_LIN_L;
+    for (int e = tid; e < 1024; e += 256) {
+        pb[e] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+        pb[1024 + e] = (red2[e] + red2[1024 + e]) + (red2[2048 + e] + red2[3072 + e]);
+    }
+    if (tid == 0) pb[2048] = (dbred[0] + dbred[1]) + (dbred[2] + dbred[3]);
+}
+static_assert(4 * 16 * SP >= 4 * 1024, "the wave staging tiles double as the 4 x 1024 reduction buffers");
+
+// tot = column sums of the partials {R, P, db4} -> out = { dW4[64][16], sum dybn3[64], sum dybn3*xhat[64], db4 }
+__global__ __launch_bounds__(1024) void dec_out_sums_finalize_kernel(const float* __restrict__ tot,
+                                                                     const float* __restrict__ w4,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     float* __restrict__ out) {
+    __shared__ float s1[1024], s2[1024];
+    const int t = threadIdx.x, c = t >> 4, tap = t & 15;
+    const float R = tot[t], P = tot[1024 + t];
+    const float gamma = scale[c] / invstd[c], beta = fmaf(scale[c], mean[c], shift[c]);
+    out[t] = fmaf(gamma, R, beta * P);
+    const float wv = w4[t];
+    s1[t] = wv * P;
+    s2[t] = wv * R;
+    __syncthreads();
+    if (tap == 0) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { a += s1[t + k]; b += s2[t + k]; }
+        out[1024 + c] = a;
+        out[1088 + c] = b;
+    }
+    if (t == 0) out[1152] = tot[2048];
+}
+
 static int rowpass_grid(long rows) {
     long g = (rows + 15) / 16;
     if (g > 1024) g = 1024;
@@ -721,6 +892,34 @@ extern "C" int cmvae_dec_out_bwd(const float* y3, const float* scale, const floa
     hipLaunchKernelGGL(dec_out_bwd_kernel<0>, dim3(bwd_sums_grid(nimg)), dim3(256), 0, (hipStream_t)stream, y3, scale, shift,
                        mean, invstd, w4, p, target, M, nimg, g_dev, gmul, none, none, dybn, part);
     return check_launch("dec_out_bwd_kernel<0>");
+}
+
+extern "C" int cmvae_dec_out_bwd_sums_partial_len(void) { cmvae::clear_stale_error(); return DEC_LIN_L; }
+extern "C" int cmvae_dec_out_bwd_sums_grid(int nimg) {
+    cmvae::clear_stale_error();
+    static const int cap = resident_blocks((const void*)dec_out_bwd_lin_kernel, 256, 1024);
+    return nimg < cap ? (nimg > 0 ? nimg : 1) : cap;
+}
+
+extern "C" int cmvae_dec_out_bwd_sums(const float* y3, const float* scale, const float* shift, const float* mean,
+                                      const float* invstd, const float* w4, const float* p, const float* target, int M,
+                                      int nimg, const float* g_dev, float gmul, float* part, float* tot, float* out,
+                                      void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(y3 && scale && shift && mean && invstd && w4 && p && target && part && tot && out,
+                  "cmvae_dec_out_bwd_sums: NULL tensor");
+    CMVAE_REQUIRE(M >= 1 && nimg >= 1 && nimg % M == 0, "cmvae_dec_out_bwd_sums: images must be a multiple of M");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = cmvae_dec_out_bwd_sums_grid(nimg);
+    hipLaunchKernelGGL(dec_out_bwd_lin_kernel, dim3(grid), dim3(256), 0, st, y3, scale, shift, mean, invstd, p, target, M,
+                       nimg, g_dev, gmul, part);
+    if (int e = check_launch("dec_out_bwd_lin_kernel")) return e;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((DEC_LIN_L + 63) / 64), dim3(1024), 0, st, (const float*)part, grid,
+                       DEC_LIN_L, tot);
+    if (int e = check_launch("colsum_reduce_kernel")) return e;
+    hipLaunchKernelGGL(dec_out_sums_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)tot, w4, scale, shift, mean,
+                       invstd, out);
+    return check_launch("dec_out_sums_finalize_kernel");
 }
 
 extern "C" int cmvae_dec_out_bwd_apply(const float* y3, const float* scale, const float* shift, const float* mean,

@@ -153,6 +153,9 @@ MULTI_PHASE = os.environ.get('CMVAE_CONV_MULTI', '1') not in ('', '0')
 # CMVAE_FUSED_BN_SUMS=0: the BatchNorm-backward sums in a pass of their own instead of the data gradient's epilogue
 FUSED_BN_SUMS = os.environ.get('CMVAE_FUSED_BN_SUMS', '1') not in ('', '0')
 
+# CMVAE_DEC_LINSUMS=0: the sums pass of the last layer's backward through the gradient tile (dec_out_bwd_kernel<0>)
+DEC_LINSUMS = os.environ.get('CMVAE_DEC_LINSUMS', '1') not in ('', '0')
+
 # CMVAE_BN_SIDE=1: the decoder's BatchNorm backward passes on a side stream next to the weight-gradient GEMMs (off by
 # default: measured slower inside the step, see _DecoderBCE.backward)
 BN_SIDE_STREAM = os.environ.get('CMVAE_BN_SIDE', '0') not in ('', '0')
@@ -210,14 +213,24 @@ class _DecoderBCE(torch.autograd.Function):
         ws = (w1, w2, w3)
         n, M, acts, folds = ctx.n, ctx.M, ctx.acts, ctx.folds
         dev = p.device
-        L = lib.cmvae_dec_out_bwd_partial_len()
-        part = torch.empty(lib.cmvae_dec_out_grid(n), L, device=dev)
         d = torch.empty(n * 196, 64, device=dev)
         g_loss = g_loss.contiguous().float()
         # pass 1: dW4, db4 and the BatchNorm-backward sums of layer 3 (the masked gradient itself is not stored)
-        check(lib.cmvae_dec_out_bwd(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n, _p(g_loss),
-                                    1.0, None, _p(part), _stream()), 'cmvae_dec_out_bwd')
-        tot = colsum(part)
+        if DEC_LINSUMS:
+            # by linearity in dlogit: two contractions over the pixels, no gradient tile (csrc/decoder_ops.hip)
+            L = lib.cmvae_dec_out_bwd_sums_partial_len()
+            part = torch.empty(lib.cmvae_dec_out_bwd_sums_grid(n), L, device=dev)
+            tot_lin = torch.empty(L, device=dev)
+            tot = torch.empty(lib.cmvae_dec_out_bwd_partial_len(), device=dev)
+            check(lib.cmvae_dec_out_bwd_sums(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
+                                             _p(g_loss), 1.0, _p(part), _p(tot_lin), _p(tot), _stream()),
+                  'cmvae_dec_out_bwd_sums')
+        else:
+            L = lib.cmvae_dec_out_bwd_partial_len()
+            part = torch.empty(lib.cmvae_dec_out_grid(n), L, device=dev)
+            check(lib.cmvae_dec_out_bwd(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
+                                        _p(g_loss), 1.0, None, _p(part), _stream()), 'cmvae_dec_out_bwd')
+            tot = colsum(part)
         dw4 = tot[:1024].reshape(64, 1, 4, 4)
         db4 = tot[1152:1153]
         sums = tot[1024:1152]

@@ -354,6 +354,16 @@ int cmvae_dec_out_fwd(const float* y3, const float* scale, const float* shift, c
 int cmvae_dec_out_bwd(const float* y3, const float* scale, const float* shift, const float* mean,
                       const float* invstd, const float* w4, const float* p, const float* target, int M, int nimg,
                       const float* g_dev, float gmul, float* dybn, float* part, void* stream);
+/* The sums pass of the last layer's backward by linearity (no gradient tile): two contractions over the pixels,
+ * R = sum m*xhat*D and P = sum m*D, give dW4 = gamma R + beta P, sum dybn3 = sum_tap w4 P, sum dybn3*xhat = sum_tap w4 R.
+ * out [1153] has the layout of cmvae_dec_out_bwd's column-summed partials { dW4[64][16], sum dybn3[64],
+ * sum dybn3*xhat[64], db4 }; part: [cmvae_dec_out_bwd_sums_grid(nimg)][cmvae_dec_out_bwd_sums_partial_len()] and
+ * tot: [partial_len] are scratch.  Same reference lines as cmvae_dec_out_bwd.                                  */
+int cmvae_dec_out_bwd_sums_partial_len(void);
+int cmvae_dec_out_bwd_sums_grid(int nimg);
+int cmvae_dec_out_bwd_sums(const float* y3, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, const float* w4, const float* p, const float* target, int M, int nimg,
+                           const float* g_dev, float gmul, float* part, float* tot, float* out, void* stream);
 /* Second pass of the same backward: with c1, c2 from cmvae_bn_bwd_finalize (computed from the sums of the first
  * pass, called with dybn == NULL) it recomputes the masked gradient and writes the gradient at layer 3's
  * pre-BatchNorm output, dy3 = scale*(dybn3 - c1 - xhat*c2), so dybn3 never travels through HBM.               */

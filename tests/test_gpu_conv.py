@@ -247,6 +247,41 @@ def test_dgrad_bn_sums_sixteen_taps_in_two_accumulating_launches(device):
     assert rel_err(mine, ref) < 1e-5
 
 
+@pytest.mark.parametrize('n,M', [(8, 4), (600, 3), (2048, 32)])
+def test_dec_out_backward_sums_by_linearity(device, n, M):
+    """cmvae_dec_out_bwd_sums (two contractions over the pixels, no gradient tile) against cmvae_dec_out_bwd (gradient
+    tile, mask and sums per row): dW4, the BatchNorm-backward sums of layer 3 and db4 to rounding; BatchNorm shifts
+    of either sign and a saturated sigmoid included."""
+    from cmvae_amd import decoder
+    from cmvae_amd._lib import lib, check
+    _p = lambda t: t.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(n)
+    y3 = (torch.randn(n * 196, 64, generator=g) * 1.5).to(device)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    mean, invstd = torch.randn(64, generator=g) * 0.3, torch.rand(64, generator=g) + 0.5
+    scale = gamma * invstd
+    fold = tuple(t.to(device) for t in (scale, beta - mean * scale, mean, invstd))
+    w4 = (torch.randn(64, 16, generator=g) * 0.2).to(device)
+    p = torch.rand(n, 784, generator=g)
+    p[0, :5] = 0.0
+    p[1, :5] = 1.0
+    p = p.to(device)
+    tgt = (torch.rand(n // M, 784, generator=g) < 0.2).float().to(device)
+    gl = torch.tensor([0.37], device=device)
+    part = torch.empty(lib.cmvae_dec_out_grid(n), lib.cmvae_dec_out_bwd_partial_len(), device=device)
+    check(lib.cmvae_dec_out_bwd(_p(y3), *(_p(t) for t in fold), _p(w4), _p(p), _p(tgt), M, n, _p(gl), 1.0, None, _p(part),
+                                st), 'cmvae_dec_out_bwd')
+    want = decoder.colsum(part)
+    L = lib.cmvae_dec_out_bwd_sums_partial_len()
+    part2 = torch.empty(lib.cmvae_dec_out_bwd_sums_grid(n), L, device=device)
+    tot, got = torch.empty(L, device=device), torch.empty(1153, device=device)
+    check(lib.cmvae_dec_out_bwd_sums(_p(y3), *(_p(t) for t in fold), _p(w4), _p(p), _p(tgt), M, n, _p(gl), 1.0, _p(part2),
+                                     _p(tot), _p(got), st), 'cmvae_dec_out_bwd_sums')
+    for sl in (slice(0, 1024), slice(1024, 1088), slice(1088, 1152), slice(1152, 1153)):
+        assert rel_err(got[sl], want[sl]) < 2e-5, sl
+
+
 def test_multi_launch_rejects_what_it_cannot_run(device):
     """More than four taps or geometries, geometries over different tensors: an error, not a launch."""
     from cmvae_amd import conv
