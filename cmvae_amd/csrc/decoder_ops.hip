@@ -244,116 +244,105 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
 // loss_part[img] = -sum_pix ( x*max(log p,-100) + (1-x)*max(log1p(-p),-100) ),  x = target[img / M]
 //
 // Per image: Y[pix][tap] = a3[pix][0:64] . w4[0:64][tap] on v_mfma_f32_16x16x4_f32 (16 pixels x 16 taps per
-// accumulator, 13 row blocks per image), then every output pixel gathers its <= 4 (pixel, tap) terms from LDS.
+// accumulator, 13 row blocks per image, operand fragments straight from global memory), then every output pixel
+// gathers its <= 4 (pixel, tap) terms from LDS.  One block barrier per image (Y is double-buffered).
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int HI = 14, HO = 28, NPIX_I = HI * HI, NPIX_O = HO * HO;
-constexpr int AL = 68;                 // pitch of the activation tile: conflict-free b128 fragment reads
 constexpr int RB = (NPIX_I + 15) / 16;  // 13 blocks of 16 pixels (12 padded rows)
 constexpr int YP = 20;                 // pitch of Y: 4*YP = 16 (mod 64) makes the accumulator stores conflict-free
 
-__global__ __launch_bounds__(256) void dec_out_fwd_kernel(const float* __restrict__ y3,
-                                                          const float* __restrict__ scale,
-                                                          const float* __restrict__ shift,
-                                                          const float* __restrict__ w4,   // [64][16]
-                                                          const float* __restrict__ b4,
-                                                          const float* __restrict__ target, int M, int nimg,
-                                                          float* __restrict__ p_out, float* __restrict__ loss_part) {
-    __shared__ __align__(16) float as[RB * 16 * AL];
-    __shared__ float ys[RB * 16 * YP];
-    __shared__ float lred[4];
+__global__ __launch_bounds__(256, 3) void dec_out_fwd_kernel(const float* __restrict__ y3,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ w4,   // [64][16]
+                                                             const float* __restrict__ b4,
+                                                             const float* __restrict__ target, int M, int nimg,
+                                                             float* __restrict__ p_out, float* __restrict__ loss_part) {
+    __shared__ float ys[2][RB * 16 * YP];            // double-buffered: one block barrier per image
+    __shared__ float lred[2][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    // B fragments: MFMA (t, j) contracts channel 16t + 4g + j on lane group g (A reads a float4 at that offset)
+    // MFMA (t, j) contracts channel 16t + 4g + j on lane group g: the A operand of a 16-pixel block is one float4 per
+    // t straight from the pixel's global row (64 contiguous bytes per pixel and t over the four lane groups) -- the
+    // activations never pass through LDS; BatchNorm + ReLU are applied on the registers.
     float bw[16];
+    float4 sc[4], sh[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bw[4 * t + j] = w4[(16 * t + 4 * g + j) * 16 + i];
-    const int q = tid & 15;
-    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+        sc[t] = *reinterpret_cast<const float4*>(scale + 16 * t + 4 * g);
+        sh[t] = *reinterpret_cast<const float4*>(shift + 16 * t + 4 * g);
+    }
     const float bias = b4[0];
-    for (int e = tid; e < (RB * 16 - NPIX_I) * AL; e += 256) as[NPIX_I * AL + e] = 0.f;
-    // the image's 196 x 16 float4 are held in registers one image ahead, so HBM latency hides under the MFMA and
-    // gather phases of the current image
-    constexpr int NLD = (NPIX_I * 16 + 255) / 256;       // 13 float4 per thread (the last one on 64 threads only)
-    float4 pre[NLD];
+    // row blocks w, w+4, w+8 (and 12 on wave 0), one image ahead in registers (two images ahead at two workgroups
+    // per CU was measured: 518 vs 485 us -- the kernel is not waiting for its loads)
+    const int nb = w == 0 ? 4 : 3;                   // uniform per wave
+    float4 pre[4][4];
     auto fetch = [&](int img) {
-        const float4* yi = reinterpret_cast<const float4*>(y3 + (long)img * NPIX_I * C);
+        const float* yi = y3 + (long)img * NPIX_I * C + 4 * g;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + 256 * k;
-            pre[k] = yi[e < NPIX_I * 16 ? e : 0];
+        for (int b = 0; b < 4; ++b) {
+            if (b < nb) {
+                const int px = 16 * (w + 4 * b) + i;
+                const float* pr = yi + (px < NPIX_I ? px : NPIX_I - 1) * C;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pre[b][t] = *reinterpret_cast<const float4*>(pr + 16 * t);
+            }
         }
     };
     if ((int)blockIdx.x < nimg) fetch(blockIdx.x);
-    for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
-        __syncthreads();
+    int buf = 0;
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x, buf ^= 1) {
+        float* yb = ys[buf];
+        typedef float floatx2 __attribute__((ext_vector_type(2)));
+        floatx4 acc[4];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + 256 * k;
-            float4 v = pre[k];
-            {
-                typedef float floatx2 __attribute__((ext_vector_type(2)));
-                const floatx2 lo = __builtin_elementwise_fma(floatx2{v.x, v.y}, floatx2{sc.x, sc.y}, floatx2{sh.x, sh.y});
-                const floatx2 hi = __builtin_elementwise_fma(floatx2{v.z, v.w}, floatx2{sc.z, sc.w}, floatx2{sh.z, sh.w});
-                v.x = fmaxf(lo.x, 0.f); v.y = fmaxf(lo.y, 0.f); v.z = fmaxf(hi.x, 0.f); v.w = fmaxf(hi.y, 0.f);
-            }
-            if (e < NPIX_I * 16) *reinterpret_cast<float4*>(&as[(e >> 4) * AL + 4 * q]) = v;
-        }
-        __syncthreads();
-        if (img + (int)gridDim.x < nimg) fetch(img + gridDim.x);
-        {
-            // row blocks w, w+4, w+8 (and 12 on wave 0): three independent accumulator chains interleaved, so a
-            // dependent MFMA never waits for the previous one of its own chain
-            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-            const float* ap = &as[(16 * w + i) * AL + 4 * g];
+        for (int b = 0; b < 4; ++b) acc[b] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * t);
-                const float4 a1 = *reinterpret_cast<const float4*>(ap + 64 * AL + 16 * t);
-                const float4 a2 = *reinterpret_cast<const float4*>(ap + 128 * AL + 16 * t);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bw[4 * t + 0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bw[4 * t + 0], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bw[4 * t + 0], acc2, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bw[4 * t + 1], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bw[4 * t + 1], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bw[4 * t + 1], acc2, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bw[4 * t + 2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bw[4 * t + 2], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, bw[4 * t + 2], acc2, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bw[4 * t + 3], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bw[4 * t + 3], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, bw[4 * t + 3], acc2, 0, 0, 0);
-            }
+        for (int t = 0; t < 4; ++t) {
+            float4 a[4];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {              // row 4g+reg of the block, tap i
-                ys[(16 * w + 4 * g + reg) * YP + i] = acc0[reg];
-                ys[(16 * (w + 4) + 4 * g + reg) * YP + i] = acc1[reg];
-                ys[(16 * (w + 8) + 4 * g + reg) * YP + i] = acc2[reg];
-            }
-            if (w == 0) {                                    // 13th row block (pixels 192..195 + padding)
-                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ap + 192 * AL + 16 * t);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bw[4 * t + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bw[4 * t + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bw[4 * t + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bw[4 * t + 3], acc, 0, 0, 0);
+            for (int b = 0; b < 4; ++b) {
+                if (b < nb) {
+                    const float4 v = pre[b][t];
+                    const floatx2 lo = __builtin_elementwise_fma(floatx2{v.x, v.y}, floatx2{sc[t].x, sc[t].y}, floatx2{sh[t].x, sh[t].y});
+                    const floatx2 hi = __builtin_elementwise_fma(floatx2{v.z, v.w}, floatx2{sc[t].z, sc[t].w}, floatx2{sh[t].z, sh[t].w});
+                    const bool ok = 16 * (w + 4 * b) + i < NPIX_I;          // padded rows of the 13th block contribute zero
+                    a[b].x = ok ? fmaxf(lo.x, 0.f) : 0.f; a[b].y = ok ? fmaxf(lo.y, 0.f) : 0.f;
+                    a[b].z = ok ? fmaxf(hi.x, 0.f) : 0.f; a[b].w = ok ? fmaxf(hi.y, 0.f) : 0.f;
                 }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) ys[(16 * 12 + 4 * g + reg) * YP + i] = acc[reg];
             }
+            // independent accumulator chains interleaved, so a dependent MFMA never waits for its own chain
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].x, bw[4 * t + 0], acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].y, bw[4 * t + 1], acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].z, bw[4 * t + 2], acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].w, bw[4 * t + 3], acc[b], 0, 0, 0);
         }
-        __syncthreads();
+        if (img + (int)gridDim.x < nimg) fetch(img + gridDim.x);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (b < nb) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) yb[(16 * (w + 4 * b) + 4 * g + reg) * YP + i] = acc[b][reg];   // row 4g+reg, tap i
+            }
+        __syncthreads();          // the image's Y is complete; the other buffer is free for the next image
         const float* tg = target + (long)(img / M) * NPIX_O;
         float lsum = 0.f;
+#if defined(CMVAE_DEC_ABL) && CMVAE_DEC_ABL == 2      // timing only: no gather phase at all
+        for (int o = tid; o < 256; o += 256) {
+#else
         for (int o = tid; o < NPIX_O; o += 256) {
+#endif
             const int oy = o / HO, ox = o - oy * HO;
             // output row oy takes kernel row ky = oy + 1 - 2*iy from input row iy: two candidates
             const int iy0 = (oy + 1) >> 1, ky0 = oy + 1 - 2 * iy0;
             const int ix0 = (ox + 1) >> 1, kx0 = ox + 1 - 2 * ix0;
-            float acc = bias;
+            float acc1 = bias;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int iy = iy0 - a, ky = ky0 + 2 * a;
@@ -362,21 +351,38 @@ __global__ __launch_bounds__(256) void dec_out_fwd_kernel(const float* __restric
                 for (int b = 0; b < 2; ++b) {
                     const int ix = ix0 - b, kx = kx0 + 2 * b;
                     if (ix < 0 || ix >= HI) continue;
-                    acc += ys[(iy * HI + ix) * YP + ky * 4 + kx];
+                    acc1 += yb[(iy * HI + ix) * YP + ky * 4 + kx];
                 }
             }
             // hardware exp / log / rcp (1 ulp-class): the loss is a sum of 784 O(1) terms per image, the tolerance
             // 1e-4 relative; log(1-p) from the rounded p like BCELoss does (saturates to the -100 clamp)
-            const float p = __frcp_rn(1.f + __expf(-acc));
+#if defined(CMVAE_DEC_ABL) && CMVAE_DEC_ABL == 1      // timing only: no transcendentals
+            const float p = acc1;
+            p_out[(long)img * NPIX_O + o] = p;
+            lsum -= tg[o] * p;
+#else
+            const float p = __frcp_rn(1.f + __expf(-acc1));
             p_out[(long)img * NPIX_O + o] = p;
             const float x = tg[o];
             lsum -= x * fmaxf(__logf(p), -100.f) + (1.f - x) * fmaxf(__logf(1.f - p), -100.f);
+#endif
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
-        if (lane == 0) lred[w] = lsum;
-        __syncthreads();
-        if (tid == 0) loss_part[img] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+        if (lane == 0) lred[buf][w] = lsum;
+        // the wave that finishes last cannot be known without a barrier: the sum of the four is written one image
+        // later, after the next image's barrier (and once more after the loop)
+        if (img != (int)blockIdx.x && tid == 0) {
+            const float* lr = lred[buf ^ 1];
+            loss_part[img - gridDim.x] = (lr[0] + lr[1]) + (lr[2] + lr[3]);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && (int)blockIdx.x < nimg) {
+        // last image this workgroup processed: index blockIdx.x + k*gridDim.x, in buffer buf ^ 1
+        const int last = blockIdx.x + ((nimg - 1 - (int)blockIdx.x) / (int)gridDim.x) * (int)gridDim.x;
+        const float* lr = lred[buf ^ 1];
+        loss_part[last] = (lr[0] + lr[1]) + (lr[2] + lr[3]);
     }
 }
 
