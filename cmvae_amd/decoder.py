@@ -1,11 +1,12 @@
 """OmniglotDecoder + Bernoulli likelihood as one autograd node on the HIP kernels
 (omniglot/module.py:43-71, omniglot/model.py:458-466).
 
-Forward:  H_rec [n,256] (channels-last: column (i*2+j)*64 + c) -> three ConvTranspose2d layers as
-sub-pixel-phase gather-GEMMs (BatchNorm statistics from the GEMM epilogue, BatchNorm+ReLU folded into
-the next layer's operand load) -> fused ConvTranspose2d(64,1)+Sigmoid+BCE.
-Backward: fused last layer (+ ReLU mask + BN-backward sums), then per layer BN-backward apply, the
-weight-gradient GEMMs, the data-gradient GEMM and the BN-backward reduction of the layer below.
+Forward:  H_rec [n,256] (channels-last: column (i*2+j)*64 + c) -> three ConvTranspose2d layers, the four
+sub-pixel phases of a layer as ONE gather-GEMM launch (BatchNorm statistics from the GEMM epilogue,
+BatchNorm+ReLU folded into the next layer's operand load) -> fused ConvTranspose2d(64,1)+Sigmoid+BCE.
+Backward: last layer in two passes (sums by linearity in dlogit, then the apply pass that writes dy3), then
+per layer: data-gradient GEMM with the BN-backward sums of the layer below from its epilogue, BN-backward
+apply of the layer below, weight gradient of all four phases in one launch.
 Pre-BatchNorm activations y1..y3 are the only tensors kept for the backward pass.
 """
 import ctypes
