@@ -237,7 +237,7 @@ class OmniglotGMVAE(_GMVAEBase):
         q_z4, log_q_z = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
         q_z = q_z4.view(B, S * M, D)
         q_eps = self.causal(ops.center_rows(q_z))
-        A = self.causal.get_w()
+        A = self.causal.get_w().contiguous()      # one layout copy for both consumers (expm_trace, elbo_tail)
         # proj: the last Linear's rows are permuted so H_rec comes out channels-last ([2,2,64] per image)
         h = torch.cat([q_z, q_eps], -1).view(-1, 2 * D)
         h = linear(h, self.proj[0].weight, self.proj[0].bias, 'elu')
@@ -329,7 +329,7 @@ class FeatureGMVAE(_GMVAEBase):
         q_z4, log_q_z = ops.reparam_logq(q_mean.contiguous(), q_logvar.contiguous(), eps)
         q_z = q_z4.view(B, S * M, D)
         q_eps = self.causal(q_z)
-        A = self.causal.get_w()
+        A = self.causal.get_w().contiguous()      # one layout copy for both consumers (expm_trace, elbo_tail)
         h = torch.cat([q_z, q_eps], -1).view(-1, 2 * D)
         for i in (0, 2):
             h = linear(h, self.proj[i].weight, self.proj[i].bias, 'relu')

@@ -376,9 +376,11 @@ class _ElboTail(torch.autograd.Function):
         h_lambda, h_c, a_lambda, rows, dim = ctx.consts
         sq, sp, sh = ctx.shapes
         dev = q_eps.device
-        zero = torch.zeros((), device=dev)
-        g = torch.stack([zero if g_kl is None else g_kl.reshape(()).float(),
-                         zero if g_h is None else g_h.reshape(()).float()])
+        parts = [None if t is None else t.reshape(()).float() for t in (g_kl, g_h)]
+        if any(t is None for t in parts):                  # an unused output: its gradient counts as zero
+            zero = torch.zeros((), device=dev)
+            parts = [zero if t is None else t for t in parts]
+        g = torch.stack(parts)
         d_q = torch.empty(sq, device=dev, dtype=torch.float32)
         d_p = torch.empty(sp, device=dev, dtype=torch.float32)
         d_e = torch.empty_like(q_eps)
