@@ -104,6 +104,7 @@ SIGNATURES = {
                                          c_void_p]),
     'cmvae_enc_conv1_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'cmvae_enc_conv1_wgrad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cmvae_enc_conv1_wgrad_bn': (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_pool_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_void_p, c_void_p, c_void_p]),

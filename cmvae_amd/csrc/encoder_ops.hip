@@ -180,6 +180,69 @@ __global__ __launch_bounds__(256) void enc_conv1_wgrad_kernel(const float* __res
     }
 }
 
+// The same with the BatchNorm-backward apply on the load: dy = scale * (dybn - c1 - xhat * c2), xhat = (y - mean) *
+// invstd.  The first layer's gradient has no other consumer (there is no data gradient below conv1), so the apply
+// pass — read dybn and y, write dy — and this kernel's read of dy become one read of dybn and y.
+__global__ __launch_bounds__(256) void enc_conv1_wgrad_bn_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dybn,
+                                                                 const float* __restrict__ y,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ c1,
+                                                                 const float* __restrict__ c2, int H, int W, long rows,
+                                                                 float* __restrict__ part) {
+    __shared__ float red[16 * 640];
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], mu = reinterpret_cast<const float4*>(mean)[q];
+    const float4 is = reinterpret_cast<const float4*>(invstd)[q];
+    const float4 a1 = reinterpret_cast<const float4*>(c1)[q], a2 = reinterpret_cast<const float4*>(c2)[q];
+    float acc[4][9], db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    const int hw = H * W;
+    for (long r = (long)blockIdx.x * 16 + rb; r < rows; r += (long)gridDim.x * 16) {
+        const long n = r / hw;
+        const int rem = (int)(r - n * hw);
+        const int py = rem / W, px = rem - py * W;
+        const float* xi = x + n * hw;
+        const float4 g4 = reinterpret_cast<const float4*>(dybn + r * EC)[q];
+        const float4 v = reinterpret_cast<const float4*>(y + r * EC)[q];
+        // the arithmetic of bn_relu_bwd_apply_kernel (masked = 1), element for element
+        const float g[4] = {sc.x * (g4.x - a1.x - (v.x - mu.x) * is.x * a2.x), sc.y * (g4.y - a1.y - (v.y - mu.y) * is.y * a2.y),
+                            sc.z * (g4.z - a1.z - (v.z - mu.z) * is.z * a2.z), sc.w * (g4.w - a1.w - (v.w - mu.w) * is.w * a2.w)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) db[c] += g[c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = py + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = px + kx - 1;
+                const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                const float xv = ok ? xi[sy * W + sx] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c][ky * 3 + kx] = fmaf(g[c], xv, acc[c][ky * 3 + kx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[rb * 640 + (4 * q + c) * 9 + t] = acc[c][t];
+        red[rb * 640 + 576 + 4 * q + c] = db[c];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 640; e += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r * 640 + e];
+        part[(long)blockIdx.x * 640 + e] = s;
+    }
+}
+
 // ------------------------------------------------------------------ relu(bn(y)) -> maxpool 2x2 (ceil)
 __device__ __forceinline__ float4 fold4(const float4 v, const float4 sc, const float4 sh) {
     return make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f),
@@ -320,6 +383,18 @@ extern "C" int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int
     hipLaunchKernelGGL(enc_conv1_wgrad_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, dy, H, W, rows,
                        part);
     return check_launch("enc_conv1_wgrad_kernel");
+}
+
+extern "C" int cmvae_enc_conv1_wgrad_bn(const float* x, const float* dybn, const float* y, const float* scale,
+                                       const float* mean, const float* invstd, const float* c1, const float* c2, int n,
+                                       int H, int W, float* part, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(x && dybn && y && scale && mean && invstd && c1 && c2 && part && n >= 1 && H >= 1 && W >= 1,
+                  "cmvae_enc_conv1_wgrad_bn: bad arguments");
+    const long rows = (long)n * H * W;
+    hipLaunchKernelGGL(enc_conv1_wgrad_bn_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, dybn, y, scale,
+                       mean, invstd, c1, c2, H, W, rows, part);
+    return check_launch("enc_conv1_wgrad_bn_kernel");
 }
 
 extern "C" int cmvae_pool_fwd(const float* y, const float* scale, const float* shift, int n, int H, int W, float* out,

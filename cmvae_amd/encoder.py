@@ -6,6 +6,8 @@ consumer permutes its weight columns instead of the data).  BatchNorm statistics
 epilogues, BatchNorm+ReLU is folded into the pooling kernel, and the backward pass recomputes the
 pooling argmax from the saved pre-BatchNorm activations.
 """
+import os
+
 import torch
 
 from . import conv
@@ -13,6 +15,8 @@ from . import dist as _dist
 from ._lib import lib, check
 from .decoder import (colsum, bn_stats_finalize, bn_eval_fold, bn_bwd_sums_finalize, bn_relu_bwd_apply, _p, _stream)
 
+# CMVAE_FUSED_CONV1_APPLY=0: layer 1's BatchNorm-backward apply as a pass of its own (A/B measurements)
+FUSED_CONV1_APPLY = os.environ.get('CMVAE_FUSED_CONV1_APPLY', '1') not in ('', '0')
 _SIZES = (28, 14, 7, 4)          # conv input sizes; pooled outputs are 14, 7, 4, 2
 TAPS = None                      # tests set this to a dict: receives the pre-BatchNorm outputs and folds of a forward
 
@@ -82,6 +86,14 @@ class _Encoder(torch.autograd.Function):
             check(lib.cmvae_pool_bwd(_p(d), _p(y), *(_p(t) for t in fold), n, H, H, _p(dybn), _p(part), _stream()),
                   'cmvae_pool_bwd')
             c1, c2, gg[li], gbe[li] = bn_bwd_sums_finalize(part, rows)
+            if li == 0 and FUSED_CONV1_APPLY:
+                # conv1's gradient feeds its weight gradient only: the BatchNorm-backward apply happens on that load
+                part = torch.empty(lib.cmvae_rowpass_grid(rows), 640, device=dev)
+                check(lib.cmvae_enc_conv1_wgrad_bn(_p(x), _p(dybn), _p(y), _p(fold[0]), _p(fold[2]), _p(fold[3]), _p(c1),
+                                                   _p(c2), n, H, H, _p(part), _stream()), 'cmvae_enc_conv1_wgrad_bn')
+                tot = colsum(part)
+                gw[0], gb[0] = tot[:576].reshape(64, 1, 3, 3), tot[576:640]
+                continue
             dy = bn_relu_bwd_apply(dybn, y, fold, c1, c2, True, out=dybn)
             if li > 0:
                 a_in = pooled[li - 1]

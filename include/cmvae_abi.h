@@ -381,6 +381,12 @@ int cmvae_dec_out_bwd_apply(const float* y3, const float* scale, const float* sh
 int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* b, int n, int H, int W,
                         float* y, float* stats_part, void* stream);
 int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, float* part, void* stream);
+/* The same straight from the masked gradient dybn and the pre-BatchNorm output y of layer 1, with the
+ * BatchNorm-backward apply dy = scale * (dybn - c1 - (y - mean) * invstd * c2) on the load: conv1's gradient has no
+ * other consumer, so the apply pass is never run for it.                                                       */
+int cmvae_enc_conv1_wgrad_bn(const float* x, const float* dybn, const float* y, const float* scale, const float* mean,
+                             const float* invstd, const float* c1, const float* c2, int n, int H, int W, float* part,
+                             void* stream);
 /* model.eval() (GMVAE.prediction, omniglot/model.py:520-531 -> module.py:14-17): Conv2d(1,64,3,1,1), BatchNorm from
  * the running statistics (scale/shift of cmvae_bn_eval_fold), ReLU and MaxPool2d(2, ceil_mode=True) in one pass:
  * x [n,H,W] -> out [n,ceil(H/2),ceil(W/2),64]; the pre-pooling activation is never written.  H, W <= 32.      */

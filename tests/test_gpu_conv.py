@@ -282,6 +282,31 @@ def test_dec_out_backward_sums_by_linearity(device, n, M):
         assert rel_err(got[sl], want[sl]) < 2e-5, sl
 
 
+def test_conv1_weight_gradient_with_the_bn_apply_on_its_load(device):
+    """Encoder layer 1: the BatchNorm-backward apply fused into the conv1 weight-gradient load gives the gradients of
+    the separate apply pass + weight gradient (same arithmetic per element, same summation order)."""
+    from cmvae_amd import encoder
+    from cmvae_amd.module import OmniglotEncoder
+    torch.manual_seed(3)
+    enc = OmniglotEncoder(64).to(device).train()
+    x = (torch.rand(48, 784, device=device) < 0.2).float()
+    gh = torch.randn(48, 256, device=device)
+    grads = []
+    for flag in (True, False):
+        encoder.FUSED_CONV1_APPLY = flag
+        try:
+            enc.zero_grad(set_to_none=True)
+            encoder.encode_images(enc, x).backward(gh)
+        finally:
+            encoder.FUSED_CONV1_APPLY = True
+        grads.append([p.grad.clone() for p in enc.parameters()])
+    scale = max(float(t.abs().max()) for t in grads[1])
+    for a, b in zip(*grads):
+        # (a conv bias in front of a BatchNorm has a zero gradient: what both sides hold there is rounding noise,
+        # so the bar is absolute, on the scale of the other gradients)
+        assert torch.equal(a, b) or rel_err(a, b) < 1e-6 or float((a - b).abs().max()) < 1e-6 * scale
+
+
 def test_multi_launch_rejects_what_it_cannot_run(device):
     """More than four taps or geometries, geometries over different tensors: an error, not a launch."""
     from cmvae_amd import conv
