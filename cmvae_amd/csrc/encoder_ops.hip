@@ -344,6 +344,255 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ layer 1 backward in ONE pass over y
+// conv1's gradient dy = scale * (dybn - c1 - c2 * xhat) feeds only its weight gradient (there is no data gradient below
+// the first layer), and that is LINEAR in dybn and xhat:
+//   dW[c][t] = scale_c * ( sum dybn*x_t  -  c1_c * sum x_t  -  c2_c * sum xhat*x_t ).
+// So the pooling backward never writes dybn: in the pass that finds the window maxima it accumulates, per channel,
+//   s1 = sum dybn, s2 = sum dybn*xhat, P1[t] = sum dybn*(x_t - m_t)
+// and enc_conv1_lin_finalize_kernel puts c1, c2 in afterwards.  The taps are CENTRED with their means m_t (known before
+// the pass, from the images alone): with raw x_t the first two terms would be a covariance taken as a difference of
+// products of means.  m_t = (1/N) sum_p x_t(p), zero padding included.  The third sum needs no pass over y at all:
+// y_c - mean_c = sum_t' w[c][t'] (x_t' - m_t') + delta_c with a constant delta_c, so
+//   sum xhat*(x_t - m_t) = invstd_c * sum_t' w[c][t'] * Gc[t'][t],   Gc = the 9x9 Gram matrix of the centred taps,
+//   sum xhat             = invstd_c * N * delta_c,                   delta_c = b_c + sum_t' w[c][t'] m_t' - mean_c
+// (delta is zero when the batch mean is this process's own, not with several ranks).
+constexpr int TAPM_BLOCKS = 256, TAPM_COLS = 64, TAPM_USED = 9 + 45;   // partials: 9 tap sums, 45 products t' <= t
+__host__ __device__ constexpr int gram_idx(int a, int b) {               // a <= b
+    return 9 + a * 9 - a * (a - 1) / 2 + (b - a);
+}
+__global__ __launch_bounds__(1024) void enc_conv1_tap_sums_kernel(const float* __restrict__ x, int H, int W, int npix,
+                                                                  float* __restrict__ part_m) {
+    __shared__ float red[16 * TAPM_USED];
+    float acc[TAPM_USED];
+#pragma unroll
+    for (int k = 0; k < TAPM_USED; ++k) acc[k] = 0.f;
+    const int hw = H * W;
+    // four pixels per trip: their 36 loads are in flight together (the kernel is a chain of load latencies otherwise)
+    for (int e0 = blockIdx.x * 1024 + threadIdx.x; e0 < npix; e0 += 4 * TAPM_BLOCKS * 1024) {
+        float xt[4][9];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * TAPM_BLOCKS * 1024;
+            const bool live = e < npix;
+            const int ee = live ? e : 0;
+            const int n = ee / hw, rem = ee - n * hw;
+            const int py = rem / W, px = rem - py * W;
+            const float* xi = x + (long)n * hw;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int sy = py + ky - 1, sx = px + kx - 1;
+                    xt[u][ky * 3 + kx] = (live && sy >= 0 && sy < H && sx >= 0 && sx < W) ? xi[sy * W + sx] : 0.f;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < 9; ++a) {
+                acc[a] += xt[u][a];
+#pragma unroll
+                for (int b = a; b < 9; ++b) acc[gram_idx(a, b)] = fmaf(xt[u][a], xt[u][b], acc[gram_idx(a, b)]);
+            }
+    }
+    // wave reduction of all 54 sums in 63 shuffles instead of 54 * 6: each step halves the values a lane carries
+    // (lanes with the offset bit set keep the upper half); lane l ends up with the wave's total of sum number l
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float v[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) v[k] = k < TAPM_USED ? acc[k] : 0.f;
+#pragma unroll
+    for (int half = 32; half >= 1; half >>= 1) {
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+            const float recv = __shfl_xor(up ? v[k] : v[k + half], half);
+            v[k] = (up ? v[k + half] : v[k]) + recv;
+        }
+    }
+    if (lane < TAPM_USED) red[w * TAPM_USED + lane] = v[0];
+    __syncthreads();
+    if (threadIdx.x < TAPM_USED) {
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 16; ++ww) v += red[ww * TAPM_USED + threadIdx.x];
+        part_m[blockIdx.x * TAPM_COLS + threadIdx.x] = v;
+    }
+}
+
+// column sums of the first ncol columns of part_m into out[] (LDS), in a fixed order: the pass and the finalize get
+// the same bits.  The whole block (>= 256 threads) calls it; buf: 256 * ncol floats of LDS.
+template <int ncol>
+__device__ __forceinline__ void tap_stats_block(const float* __restrict__ part_m, float* buf, float* out) {
+    const int tid = threadIdx.x;
+    if (tid < TAPM_BLOCKS) {
+        float v[ncol];
+#pragma unroll
+        for (int k = 0; k < ncol; ++k) v[k] = part_m[tid * TAPM_COLS + k];
+#pragma unroll
+        for (int k = 0; k < ncol; ++k) buf[k * TAPM_BLOCKS + tid] = v[k];
+    }
+    __syncthreads();
+    if (tid < ncol) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int b = 0; b < TAPM_BLOCKS; b += 4) {
+            s0 += buf[tid * TAPM_BLOCKS + b]; s1 += buf[tid * TAPM_BLOCKS + b + 1];
+            s2 += buf[tid * TAPM_BLOCKS + b + 2]; s3 += buf[tid * TAPM_BLOCKS + b + 3];
+        }
+        out[tid] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+}
+
+constexpr int LIN1_COLS = 2 * EC + 9 * EC;           // s1, s2 [64] each, P1 [64][9]
+__global__ __launch_bounds__(256) void enc_conv1_bwd_lin_kernel(
+    const float* __restrict__ d_pool, const float* __restrict__ y, const float* __restrict__ x,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ part_m, float npix_loc, int H, int W, int Ho, int Wo,
+    long orows, float* __restrict__ part) {
+    __shared__ float red[4 * LIN1_COLS];             // first the scratch of tap_stats_block (256 * 9 floats)
+    __shared__ float ms[9];
+    static_assert(4 * LIN1_COLS >= TAPM_BLOCKS * 9, "scratch");
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4, lane = threadIdx.x & 63;
+    tap_stats_block<9>(part_m, red, ms);
+    float m[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) m[t] = ms[t] / npix_loc;      // the finalize kernel's expression, bit for bit
+    __syncthreads();                                 // red is reused for the final reduction
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    const float4 mu4 = reinterpret_cast<const float4*>(mean)[q], is4 = reinterpret_cast<const float4*>(invstd)[q];
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+    float s1[4], s2[4], P1[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s1[c] = s2[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) P1[c][t] = 0.f;
+    }
+    const int ohw = Ho * Wo;
+    const int pa = q >> 2, pb = q & 3;               // this thread's element of the window's 4x4 image patch
+    // (every thread runs the same number of iterations: the patch is exchanged with shuffles)
+    const long r_end = ((orows + 15) / 16) * 16;
+    for (long r = (long)blockIdx.x * 16 + rb; r < r_end; r += (long)gridDim.x * 16) {
+        const bool live = r < orows;
+        const long rr = live ? r : orows - 1;
+        const long n = rr / ohw;
+        const int rem = (int)(rr - n * ohw);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        float4 g4 = reinterpret_cast<const float4*>(d_pool + rr * EC)[q];
+        if (!live) g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float raw[4][4], val[4][4];        // [window slot][channel]
+        bool in[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sy = 2 * oy + (s >> 1), sx = 2 * ox + (s & 1);
+            in[s] = sy < H && sx < W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in[s]) v = reinterpret_cast<const float4*>(y + ((n * H + sy) * W + sx) * EC)[q];
+            const float4 f = fold4(v, sc, sh);
+            raw[s][0] = v.x; raw[s][1] = v.y; raw[s][2] = v.z; raw[s][3] = v.w;
+            val[s][0] = f.x; val[s][1] = f.y; val[s][2] = f.z; val[s][3] = f.w;
+        }
+        // the 4x4 patch of the image around the window (zero outside the image): one element per thread of the
+        // window's 16, handed round
+        float xp[4][4];
+        {
+            const int sy = 2 * oy - 1 + pa, sx = 2 * ox - 1 + pb;
+            const float mine = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(n * H + sy) * W + sx] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xp[j >> 2][j & 3] = __shfl(mine, (lane & 48) | j);
+        }
+        float o[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int best = 0;
+            float bv = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (in[s] && val[s][c] > bv) { bv = val[s][c]; best = s; }
+            const float gg = bv > 0.f ? g[c] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                o[s][c] = (s == best) ? gg : 0.f;
+                s2[c] = fmaf(o[s][c], (raw[s][c] - mu[c]) * is[c], s2[c]);
+            }
+            s1[c] += gg;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!in[s]) continue;          // a pixel outside the image has no taps
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float xc = xp[(s >> 1) + ky][(s & 1) + kx] - m[ky * 3 + kx];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) P1[c][ky * 3 + kx] = fmaf(o[s][c], xc, P1[c][ky * 3 + kx]);
+                }
+        }
+    }
+    // the four window slots of a wave share q: two shuffles, then the four waves through LDS
+    const int w = threadIdx.x >> 6;
+    auto put = [&](int col, float v) {
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) red[w * LIN1_COLS + col] = v;
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        put(4 * q + c, s1[c]);
+        put(EC + 4 * q + c, s2[c]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) put(2 * EC + (4 * q + c) * 9 + t, P1[c][t]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < LIN1_COLS; e += 256)
+        part[(long)blockIdx.x * LIN1_COLS + e] =
+            (red[e] + red[LIN1_COLS + e]) + (red[2 * LIN1_COLS + e] + red[3 * LIN1_COLS + e]);
+}
+
+// tot [LIN1_COLS]: this rank's column sums of the partials; sums_glob [128]: {s1, s2} over all ranks (tot itself in a
+// single process); count_glob / npix_loc: values per channel over all ranks / on this rank; w [64][9], b [64]: conv1.
+__global__ __launch_bounds__(640) void enc_conv1_lin_finalize_kernel(
+    const float* __restrict__ tot, const float* __restrict__ sums_glob, float count_glob, float npix_loc,
+    const float* __restrict__ part_m, const float* __restrict__ w, const float* __restrict__ b,
+    const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float buf[TAPM_BLOCKS * TAPM_USED];
+    __shared__ float st[TAPM_USED];
+    tap_stats_block<TAPM_USED>(part_m, buf, st);
+    const int e = threadIdx.x;
+    float m[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) m[t] = st[t] / npix_loc;
+    const int c = e < 9 * EC ? e / 9 : e - 9 * EC;
+    const float c1 = sums_glob[c] / count_glob, c2 = sums_glob[EC + c] / count_glob;
+    const float s1 = tot[c], s2 = tot[EC + c];
+    float wm = b[c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wm = fmaf(w[c * 9 + t], m[t], wm);
+    const float s3 = invstd[c] * npix_loc * (wm - mean[c]);     // sum xhat over this rank's pixels
+    const float r1 = s1 - c1 * npix_loc;            // zero in a single process (c1 is then this rank's mean of dybn)
+    if (e < 9 * EC) {
+        const int t = e - 9 * c;
+        float p3 = 0.f;                             // sum xhat * (x_t - m_t)
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+            const float gc = st[a <= t ? gram_idx(a, t) : gram_idx(t, a)] - npix_loc * m[a] * m[t];
+            p3 = fmaf(w[c * 9 + a], gc, p3);
+        }
+        p3 *= invstd[c];
+        const float p1 = tot[2 * EC + e];
+        dW[e] = scale[c] * ((p1 + m[t] * r1) - c2 * (p3 + m[t] * s3));
+    } else {
+        db[c] = scale[c] * (r1 - c2 * s3);
+        dgamma[c] = s2;
+        dbeta[c] = s1;
+    }
+}
+
 static int rp_grid(long rows) {
     long g = (rows + 15) / 16;
     if (g > 1024) g = 1024;
@@ -395,6 +644,43 @@ extern "C" int cmvae_enc_conv1_wgrad_bn(const float* x, const float* dybn, const
     hipLaunchKernelGGL(enc_conv1_wgrad_bn_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, dybn, y, scale,
                        mean, invstd, c1, c2, H, W, rows, part);
     return check_launch("enc_conv1_wgrad_bn_kernel");
+}
+
+extern "C" int cmvae_enc_conv1_bwd_lin_cols(void) { cmvae::clear_stale_error(); return LIN1_COLS; }
+
+extern "C" int cmvae_enc_conv1_tap_sums(const float* x, int n, int H, int W, float* part_m, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(x && part_m && n >= 1 && H >= 1 && W >= 1 && (long)n * H * W < (1L << 30),
+                  "cmvae_enc_conv1_tap_sums: bad arguments");
+    hipLaunchKernelGGL(enc_conv1_tap_sums_kernel, dim3(TAPM_BLOCKS), dim3(1024), 0, (hipStream_t)stream, x, H, W,
+                       n * H * W, part_m);
+    return check_launch("enc_conv1_tap_sums_kernel");
+}
+
+extern "C" int cmvae_enc_conv1_bwd_lin(const float* d_pool, const float* y, const float* x, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd, const float* part_m,
+                                      int n, int H, int W, float* part, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(d_pool && y && x && scale && shift && mean && invstd && part_m && part && n >= 1 && H >= 1 && W >= 1,
+                  "cmvae_enc_conv1_bwd_lin: bad arguments");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long orows = (long)n * Ho * Wo;
+    hipLaunchKernelGGL(enc_conv1_bwd_lin_kernel, dim3(rp_grid(orows)), dim3(256), 0, (hipStream_t)stream, d_pool, y, x,
+                       scale, shift, mean, invstd, part_m, (float)((long)n * H * W), H, W, Ho, Wo, orows, part);
+    return check_launch("enc_conv1_bwd_lin_kernel");
+}
+
+extern "C" int cmvae_enc_conv1_lin_finalize(const float* tot, const float* sums_glob, float count_glob, int n, int H,
+                                           int W, const float* part_m, const float* w, const float* b,
+                                           const float* scale, const float* mean, const float* invstd, float* dW,
+                                           float* db, float* dgamma, float* dbeta, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(tot && sums_glob && part_m && w && b && scale && mean && invstd && dW && db && dgamma && dbeta &&
+                      n >= 1 && count_glob >= 1.f,
+                  "cmvae_enc_conv1_lin_finalize: bad arguments");
+    hipLaunchKernelGGL(enc_conv1_lin_finalize_kernel, dim3(1), dim3(640), 0, (hipStream_t)stream, tot, sums_glob,
+                       count_glob, (float)((long)n * H * W), part_m, w, b, scale, mean, invstd, dW, db, dgamma, dbeta);
+    return check_launch("enc_conv1_lin_finalize_kernel");
 }
 
 extern "C" int cmvae_pool_fwd(const float* y, const float* scale, const float* shift, int n, int H, int W, float* out,

@@ -17,6 +17,8 @@ from .decoder import (colsum, bn_stats_finalize, bn_eval_fold, bn_bwd_sums_final
 
 # CMVAE_FUSED_CONV1_APPLY=0: layer 1's BatchNorm-backward apply as a pass of its own (A/B measurements)
 FUSED_CONV1_APPLY = os.environ.get('CMVAE_FUSED_CONV1_APPLY', '1') not in ('', '0')
+# CMVAE_CONV1_LINSUMS=0: layer 1's pooling backward writes dybn and the weight gradient reads it back (A/B measurements)
+CONV1_LINSUMS = os.environ.get('CMVAE_CONV1_LINSUMS', '1') not in ('', '0')
 _SIZES = (28, 14, 7, 4)          # conv input sizes; pooled outputs are 14, 7, 4, 2
 TAPS = None                      # tests set this to a dict: receives the pre-BatchNorm outputs and folds of a forward
 
@@ -63,14 +65,14 @@ class _Encoder(torch.autograd.Function):
         ctx.ys, ctx.folds, ctx.pooled = ys, folds, pooled
         if TAPS is not None:
             TAPS['enc'] = (ys, folds)
-        ctx.save_for_backward(x, w2, w3, w4)
+        ctx.save_for_backward(x, w2, w3, w4, w1, b1)
         return a.view(n, 256)
 
     @staticmethod
     def backward(ctx, d_h):
         if not ctx.training:
             raise RuntimeError('cmvae_amd: encoder backward is only defined in training mode (batch statistics)')
-        x, w2, w3, w4 = ctx.saved_tensors
+        x, w2, w3, w4, w1, b1 = ctx.saved_tensors
         ws = (None, w2, w3, w4)
         n, ys, folds, pooled = ctx.n, ctx.ys, ctx.folds, ctx.pooled
         dev = x.device
@@ -81,6 +83,24 @@ class _Encoder(torch.autograd.Function):
             Ho = (H + 1) // 2
             rows = n * H * H
             y, fold = ys[li], folds[li]
+            if li == 0 and CONV1_LINSUMS:
+                # the weight gradient is linear in dybn and xhat: one pass over y accumulates everything, dybn is
+                # never written (cmvae_enc_conv1_bwd_lin); c1, c2 enter in the finalize
+                part_m = torch.empty(256, 64, device=dev)
+                check(lib.cmvae_enc_conv1_tap_sums(_p(x), n, H, H, _p(part_m), _stream()), 'cmvae_enc_conv1_tap_sums')
+                part = torch.empty(lib.cmvae_rowpass_grid(n * Ho * Ho), lib.cmvae_enc_conv1_bwd_lin_cols(), device=dev)
+                check(lib.cmvae_enc_conv1_bwd_lin(_p(d), _p(y), _p(x), *(_p(t) for t in fold), _p(part_m), n, H, H,
+                                                  _p(part), _stream()), 'cmvae_enc_conv1_bwd_lin')
+                tot = colsum(part)
+                sums_glob = _dist.global_sums(tot[:128])
+                dW, gb[0], gg[0], gbe[0] = (torch.empty(k, device=dev) for k in (576, 64, 64, 64))
+                check(lib.cmvae_enc_conv1_lin_finalize(_p(tot), _p(sums_glob), float(rows * _dist.world_size()), n, H, H,
+                                                       _p(part_m), _p(w1.detach().reshape(64, 9)), _p(b1.detach()),
+                                                       _p(fold[0]), _p(fold[2]), _p(fold[3]), _p(dW), _p(gb[0]),
+                                                       _p(gg[0]), _p(gbe[0]), _stream()),
+                      'cmvae_enc_conv1_lin_finalize')
+                gw[0] = dW.reshape(64, 1, 3, 3)
+                continue
             dybn = torch.empty(rows, 64, device=dev)
             part = torch.empty(lib.cmvae_rowpass_grid(n * Ho * Ho), 128, device=dev)
             check(lib.cmvae_pool_bwd(_p(d), _p(y), *(_p(t) for t in fold), n, H, H, _p(dybn), _p(part), _stream()),

@@ -387,6 +387,26 @@ int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, 
 int cmvae_enc_conv1_wgrad_bn(const float* x, const float* dybn, const float* y, const float* scale, const float* mean,
                              const float* invstd, const float* c1, const float* c2, int n, int H, int W, float* part,
                              void* stream);
+/* Layer 1's whole backward (autograd of omniglot/module.py:14-17 for the first conv block) in one pass over y: the
+ * weight gradient is linear in dybn and xhat, so the pooling backward accumulates per channel s1 = sum dybn,
+ * s2 = sum dybn*xhat, P1[t] = sum dybn*(x_t - m_t) and never writes dybn; m_t = mean of tap t of the images (zero
+ * padding included).  cmvae_enc_conv1_tap_sums: part_m [256][64] = partial {sum x_t [9], sum x_t'*x_t [45, t' <= t]}.
+ * part [cmvae_rowpass_grid(n*Ho*Wo)][cmvae_enc_conv1_bwd_lin_cols()]: {s1, s2}[64], P1 [64][9].
+ * cmvae_enc_conv1_lin_finalize: tot = column sums of part (this rank), sums_glob [128] = {s1, s2} summed over the
+ * ranks (tot itself in one process), count_glob = values per channel over all ranks, w [64][9], b [64] = conv1;
+ * sum xhat*(x_t - m_t) = invstd_c * sum_t' w[c][t'] Gc[t'][t] (Gc: Gram matrix of the centred taps) and
+ * s3 = sum xhat = invstd_c * N * (b_c + sum_t' w[c][t'] m_t' - mean_c) follow from y = conv1(x):
+ *   dW[c][t] = scale_c * (P1 + m_t*(s1 - c1*N) - c2*(P3 + m_t*s3)),  db = scale_c * (s1 - c1*N - c2*s3),
+ *   dgamma = s2, dbeta = s1,  c1 = sums_glob[c]/count_glob, c2 = sums_glob[64+c]/count_glob, N = n*H*W.            */
+int cmvae_enc_conv1_bwd_lin_cols(void);
+int cmvae_enc_conv1_tap_sums(const float* x, int n, int H, int W, float* part_m, void* stream);
+int cmvae_enc_conv1_bwd_lin(const float* d_pool, const float* y, const float* x, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, const float* part_m, int n, int H, int W, float* part,
+                            void* stream);
+int cmvae_enc_conv1_lin_finalize(const float* tot, const float* sums_glob, float count_glob, int n, int H, int W,
+                                 const float* part_m, const float* w, const float* b, const float* scale,
+                                 const float* mean, const float* invstd, float* dW, float* db, float* dgamma,
+                                 float* dbeta, void* stream);
 /* model.eval() (GMVAE.prediction, omniglot/model.py:520-531 -> module.py:14-17): Conv2d(1,64,3,1,1), BatchNorm from
  * the running statistics (scale/shift of cmvae_bn_eval_fold), ReLU and MaxPool2d(2, ceil_mode=True) in one pass:
  * x [n,H,W] -> out [n,ceil(H/2),ceil(W/2),64]; the pre-pooling activation is never written.  H, W <= 32.      */
