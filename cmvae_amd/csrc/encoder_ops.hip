@@ -9,7 +9,8 @@ namespace cmvae {
 constexpr int EC = 64;
 
 // ------------------------------------------------------------------ conv 1->64, 3x3, pad 1
-// x [n,H,W]; w [64][9]; y [n*H*W, 64]; part[blk][128] = {sum y, sum y^2} (optional).
+// x [n,H,W]; w [64][9]; y [n*H*W, 64] (nullptr: statistics only, y is recomputed by its consumers);
+// part[blk][128] = {sum y, sum y^2} (optional).
 // One image per workgroup pass: the image sits zero-padded in LDS (taps never branch, 16 lanes broadcast-read one
 // pixel), a thread owns 4 channels and writes one float4 of a 256-B output row -> HBM-bound on the 64-channel output.
 constexpr int EC1_MAX = 34 * 34;       // padded image, H, W <= 32
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void enc_conv1_fwd_kernel(const float* __restr
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, wr[c][ky * 3 + kx], acc[c]);
                 }
-            reinterpret_cast<float4*>(yi + pix * EC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (y) reinterpret_cast<float4*>(yi + pix * EC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) { s1[c] += acc[c]; s2[c] = fmaf(acc[c], acc[c], s2[c]); }
             px += 16;
@@ -553,6 +554,127 @@ __global__ __launch_bounds__(256) void enc_conv1_bwd_lin_kernel(
             (red[e] + red[LIN1_COLS + e]) + (red[2 * LIN1_COLS + e] + red[3 * LIN1_COLS + e]);
 }
 
+// The same pass with y recomputed from the image (conv1 is 9 multiply-adds per value; the arithmetic of
+// enc_conv1_fwd_kernel / enc_conv1_pool_kernel, bit for bit, so the window maxima are the forward's): the 64-channel
+// pre-pooling activation of layer 1 is never stored.  One image per workgroup pass, zero-padded in LDS.
+__global__ __launch_bounds__(256) void enc_conv1_bwd_lin_rc_kernel(
+    const float* __restrict__ d_pool, const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ b, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ part_m, float npix_loc,
+    int H, int W, int nimg, float* __restrict__ part) {
+    __shared__ float red[4 * LIN1_COLS];
+    __shared__ float ms[9];
+    __shared__ float xs[36 * 36];
+    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4, lane = threadIdx.x & 63;
+    tap_stats_block<9>(part_m, red, ms);
+    float m[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) m[t] = ms[t] / npix_loc;
+    float wr[4][9], br[4], sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        br[c] = b[4 * q + c]; sc[c] = scale[4 * q + c]; sh[c] = shift[4 * q + c];
+        mu[c] = mean[4 * q + c]; is[c] = invstd[4 * q + c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[c][t] = w[(4 * q + c) * 9 + t];
+    }
+    float s1[4], s2[4], P1[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        s1[c] = s2[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) P1[c][t] = 0.f;
+    }
+    const int hw = H * W, PW = W + 4, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    for (int e = threadIdx.x; e < (H + 4) * PW; e += 256) xs[e] = 0.f;
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+        __syncthreads();
+        const float* xi = x + (long)img * hw;
+        for (int e = threadIdx.x; e < hw; e += 256) {
+            const int py = e / W;
+            xs[(py + 1) * PW + (e - py * W) + 1] = xi[e];
+        }
+        __syncthreads();
+        const float* gi = d_pool + (long)img * Ho * Wo * EC;
+        for (int op = rb; op < Ho * Wo; op += 16) {
+            const int oy = op / Wo, ox = op - oy * Wo;
+            const float4 g4 = reinterpret_cast<const float4*>(gi + op * EC)[q];
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            const float* xp0 = &xs[(2 * oy) * PW + 2 * ox];      // 4x4 input patch of the 2x2 window
+            float xp[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xp[i][j] = xp0[i * PW + j];
+            float raw[4][4], val[4][4];    // [window slot][channel]
+            bool in[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                in[s] = (2 * oy + (s >> 1) < H) && (2 * ox + (s & 1) < W);
+                float acc[4] = {br[0], br[1], br[2], br[3]};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[c] = fmaf(xp[(s >> 1) + ky][(s & 1) + kx], wr[c][ky * 3 + kx], acc[c]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    raw[s][c] = acc[c];
+                    val[s][c] = fmaxf(fmaf(acc[c], sc[c], sh[c]), 0.f);
+                }
+            }
+            float o[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                int best = 0;
+                float bv = -INFINITY;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (in[s] && val[s][c] > bv) { bv = val[s][c]; best = s; }
+                const float gg = bv > 0.f ? g[c] : 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    o[s][c] = (s == best) ? gg : 0.f;
+                    s2[c] = fmaf(o[s][c], (raw[s][c] - mu[c]) * is[c], s2[c]);
+                }
+                s1[c] += gg;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (!in[s]) continue;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float xc = xp[(s >> 1) + ky][(s & 1) + kx] - m[ky * 3 + kx];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) P1[c][ky * 3 + kx] = fmaf(o[s][c], xc, P1[c][ky * 3 + kx]);
+                    }
+            }
+        }
+    }
+    __syncthreads();                                 // red: the scratch of tap_stats_block is free again
+    const int wv = threadIdx.x >> 6;
+    auto put = [&](int col, float v) {
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) red[wv * LIN1_COLS + col] = v;
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        put(4 * q + c, s1[c]);
+        put(EC + 4 * q + c, s2[c]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) put(2 * EC + (4 * q + c) * 9 + t, P1[c][t]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < LIN1_COLS; e += 256)
+        part[(long)blockIdx.x * LIN1_COLS + e] =
+            (red[e] + red[LIN1_COLS + e]) + (red[2 * LIN1_COLS + e] + red[3 * LIN1_COLS + e]);
+}
+
 // tot [LIN1_COLS]: this rank's column sums of the partials; sums_glob [128]: {s1, s2} over all ranks (tot itself in a
 // single process); count_glob / npix_loc: values per channel over all ranks / on this rank; w [64][9], b [64]: conv1.
 __global__ __launch_bounds__(640) void enc_conv1_lin_finalize_kernel(
@@ -606,7 +728,7 @@ using namespace cmvae;
 extern "C" int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* b, int n, int H, int W, float* y,
                                    float* stats_part, void* stream) {
     cmvae::clear_stale_error();
-    CMVAE_REQUIRE(x && w && b && y && n >= 1 && H >= 1 && W >= 1 && H <= 32 && W <= 32,
+    CMVAE_REQUIRE(x && w && b && (y || stats_part) && n >= 1 && H >= 1 && W >= 1 && H <= 32 && W <= 32,
                   "cmvae_enc_conv1_fwd: bad arguments (images up to 32x32)");
     const long rows = (long)n * H * W;
     hipLaunchKernelGGL(enc_conv1_fwd_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, w, b, H, W, n,
@@ -668,6 +790,21 @@ extern "C" int cmvae_enc_conv1_bwd_lin(const float* d_pool, const float* y, cons
     hipLaunchKernelGGL(enc_conv1_bwd_lin_kernel, dim3(rp_grid(orows)), dim3(256), 0, (hipStream_t)stream, d_pool, y, x,
                        scale, shift, mean, invstd, part_m, (float)((long)n * H * W), H, W, Ho, Wo, orows, part);
     return check_launch("enc_conv1_bwd_lin_kernel");
+}
+
+extern "C" int cmvae_enc_conv1_bwd_lin_rc_grid(int n) { cmvae::clear_stale_error(); return n < 2048 ? (n < 1 ? 1 : n) : 2048; }
+
+extern "C" int cmvae_enc_conv1_bwd_lin_rc(const float* d_pool, const float* x, const float* w, const float* b,
+                                         const float* scale, const float* shift, const float* mean, const float* invstd,
+                                         const float* part_m, int n, int H, int W, float* part, void* stream) {
+    cmvae::clear_stale_error();
+    CMVAE_REQUIRE(d_pool && x && w && b && scale && shift && mean && invstd && part_m && part && n >= 1,
+                  "cmvae_enc_conv1_bwd_lin_rc: bad arguments");
+    CMVAE_REQUIRE(H >= 1 && W >= 1 && H <= 32 && W <= 32, "cmvae_enc_conv1_bwd_lin_rc: image %dx%d exceeds 32x32", H, W);
+    const int grid = n < 2048 ? n : 2048;
+    hipLaunchKernelGGL(enc_conv1_bwd_lin_rc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_pool, x, w, b, scale,
+                       shift, mean, invstd, part_m, (float)((long)n * H * W), H, W, n, part);
+    return check_launch("enc_conv1_bwd_lin_rc_kernel");
 }
 
 extern "C" int cmvae_enc_conv1_lin_finalize(const float* tot, const float* sums_glob, float count_glob, int n, int H,

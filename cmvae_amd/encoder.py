@@ -19,6 +19,9 @@ from .decoder import (colsum, bn_stats_finalize, bn_eval_fold, bn_bwd_sums_final
 FUSED_CONV1_APPLY = os.environ.get('CMVAE_FUSED_CONV1_APPLY', '1') not in ('', '0')
 # CMVAE_CONV1_LINSUMS=0: layer 1's pooling backward writes dybn and the weight gradient reads it back (A/B measurements)
 CONV1_LINSUMS = os.environ.get('CMVAE_CONV1_LINSUMS', '1') not in ('', '0')
+# CMVAE_CONV1_RECOMPUTE=0: the training step stores layer 1's pre-pooling activation y1 (241 MB at 1200 images) instead
+# of recomputing it from the images in the pooling pass and in the backward pass (needs CONV1_LINSUMS)
+CONV1_RECOMPUTE = os.environ.get('CMVAE_CONV1_RECOMPUTE', '1') not in ('', '0')
 _SIZES = (28, 14, 7, 4)          # conv input sizes; pooled outputs are 14, 7, 4, 2
 TAPS = None                      # tests set this to a dict: receives the pre-BatchNorm outputs and folds of a forward
 
@@ -44,6 +47,24 @@ class _Encoder(torch.autograd.Function):
                                                    _p(fold[1]), n, H, H, _p(a), _stream()), 'cmvae_enc_conv1_pool_fwd')
                 ys.append(None); folds.append(fold); pooled.append(a)
                 continue
+            if li == 0 and training and CONV1_RECOMPUTE and CONV1_LINSUMS:
+                # y1 is never stored: batch statistics from a pass that only sums, then conv1 + BatchNorm + ReLU +
+                # pooling in one pass (the evaluation kernel with the batch fold); the backward recomputes y1 too
+                part = torch.empty(lib.cmvae_rowpass_grid(rows), 128, device=dev)
+                w9, b1d = w1.detach().reshape(64, 9), b1.detach()
+                check(lib.cmvae_enc_conv1_fwd(_p(x), _p(w9), _p(b1d), n, H, H, None, _p(part), _stream()),
+                      'cmvae_enc_conv1_fwd')
+                fold = bn_stats_finalize(part, rows * world, bns[0])
+                a = torch.empty(n * Ho * Ho, 64, device=dev)
+                check(lib.cmvae_enc_conv1_pool_fwd(_p(x), _p(w9), _p(b1d), _p(fold[0]), _p(fold[1]), n, H, H, _p(a),
+                                                   _stream()), 'cmvae_enc_conv1_pool_fwd')
+                y = None
+                if TAPS is not None:                       # tests look at the pre-BatchNorm outputs
+                    y = torch.empty(rows, 64, device=dev)
+                    check(lib.cmvae_enc_conv1_fwd(_p(x), _p(w9), _p(b1d), n, H, H, _p(y), None, _stream()),
+                          'cmvae_enc_conv1_fwd')
+                ys.append(y); folds.append(fold); pooled.append(a)
+                continue
             y = torch.empty(rows, 64, device=dev)
             part = None
             if li == 0:
@@ -62,6 +83,7 @@ class _Encoder(torch.autograd.Function):
             check(lib.cmvae_pool_fwd(_p(y), _p(fold[0]), _p(fold[1]), n, H, H, _p(a), _stream()), 'cmvae_pool_fwd')
             ys.append(y); folds.append(fold); pooled.append(a)
         ctx.training, ctx.n = training, n
+        ctx.recompute = bool(training and CONV1_RECOMPUTE and CONV1_LINSUMS)      # y1 was not stored
         ctx.ys, ctx.folds, ctx.pooled = ys, folds, pooled
         if TAPS is not None:
             TAPS['enc'] = (ys, folds)
@@ -83,14 +105,22 @@ class _Encoder(torch.autograd.Function):
             Ho = (H + 1) // 2
             rows = n * H * H
             y, fold = ys[li], folds[li]
-            if li == 0 and CONV1_LINSUMS:
+            if li == 0 and (CONV1_LINSUMS or ctx.recompute):
                 # the weight gradient is linear in dybn and xhat: one pass over y accumulates everything, dybn is
                 # never written (cmvae_enc_conv1_bwd_lin); c1, c2 enter in the finalize
                 part_m = torch.empty(256, 64, device=dev)
                 check(lib.cmvae_enc_conv1_tap_sums(_p(x), n, H, H, _p(part_m), _stream()), 'cmvae_enc_conv1_tap_sums')
-                part = torch.empty(lib.cmvae_rowpass_grid(n * Ho * Ho), lib.cmvae_enc_conv1_bwd_lin_cols(), device=dev)
-                check(lib.cmvae_enc_conv1_bwd_lin(_p(d), _p(y), _p(x), *(_p(t) for t in fold), _p(part_m), n, H, H,
-                                                  _p(part), _stream()), 'cmvae_enc_conv1_bwd_lin')
+                if ctx.recompute:
+                    part = torch.empty(lib.cmvae_enc_conv1_bwd_lin_rc_grid(n), lib.cmvae_enc_conv1_bwd_lin_cols(),
+                                       device=dev)
+                    check(lib.cmvae_enc_conv1_bwd_lin_rc(_p(d), _p(x), _p(w1.detach().reshape(64, 9)), _p(b1.detach()),
+                                                         *(_p(t) for t in fold), _p(part_m), n, H, H, _p(part),
+                                                         _stream()), 'cmvae_enc_conv1_bwd_lin_rc')
+                else:
+                    part = torch.empty(lib.cmvae_rowpass_grid(n * Ho * Ho), lib.cmvae_enc_conv1_bwd_lin_cols(),
+                                       device=dev)
+                    check(lib.cmvae_enc_conv1_bwd_lin(_p(d), _p(y), _p(x), *(_p(t) for t in fold), _p(part_m), n, H, H,
+                                                      _p(part), _stream()), 'cmvae_enc_conv1_bwd_lin')
                 tot = colsum(part)
                 sums_glob = _dist.global_sums(tot[:128])
                 dW, gb[0], gg[0], gbe[0] = (torch.empty(k, device=dev) for k in (576, 64, 64, 64))

@@ -403,6 +403,14 @@ int cmvae_enc_conv1_tap_sums(const float* x, int n, int H, int W, float* part_m,
 int cmvae_enc_conv1_bwd_lin(const float* d_pool, const float* y, const float* x, const float* scale, const float* shift,
                             const float* mean, const float* invstd, const float* part_m, int n, int H, int W, float* part,
                             void* stream);
+/* cmvae_enc_conv1_bwd_lin with y recomputed from the images (the arithmetic of cmvae_enc_conv1_fwd, bit for bit): the
+ * training step then never stores layer 1's pre-pooling activation (cmvae_enc_conv1_fwd with y = NULL for the batch
+ * statistics, cmvae_enc_conv1_pool_fwd with the batch fold for the pooled output).
+ * part [cmvae_enc_conv1_bwd_lin_rc_grid(n)][cmvae_enc_conv1_bwd_lin_cols()].                                       */
+int cmvae_enc_conv1_bwd_lin_rc_grid(int n);
+int cmvae_enc_conv1_bwd_lin_rc(const float* d_pool, const float* x, const float* w, const float* b, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, const float* part_m, int n,
+                               int H, int W, float* part, void* stream);
 int cmvae_enc_conv1_lin_finalize(const float* tot, const float* sums_glob, float count_glob, int n, int H, int W,
                                  const float* part_m, const float* w, const float* b, const float* scale,
                                  const float* mean, const float* invstd, float* dW, float* db, float* dgamma,
