@@ -280,7 +280,11 @@ __global__ __launch_bounds__(256, 3) void dec_out_fwd_kernel(const float* __rest
     const int nb = w == 0 ? 4 : 3;                   // uniform per wave
     float4 pre[4][4];
     auto fetch = [&](int img) {
+#if defined(CMVAE_DEC_ABL) && CMVAE_DEC_ABL == 3      // timing only: the activations come from 32 images (L2 hits)
+        const float* yi = y3 + (long)(img & 31) * NPIX_I * C + 4 * g;
+#else
         const float* yi = y3 + (long)img * NPIX_I * C + 4 * g;
+#endif
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             if (b < nb) {
@@ -657,7 +661,11 @@ __global__ __launch_bounds__(256, 3) void dec_out_bwd_lin_kernel(const float* __
         }
     };
     auto fetch_rows = [&](int img, int rbk) {
+#if defined(CMVAE_DEC_ABL) && CMVAE_DEC_ABL == 3      // timing only: the activations come from 32 images (L2 hits)
+        const float* yi = y3 + (long)(img & 31) * NPIX_I * C;
+#else
         const float* yi = y3 + (long)img * NPIX_I * C;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int px = 16 * rbk + g + 4 * j;
