@@ -56,6 +56,7 @@ struct ConvGeom {
     // and measured as well: it keeps the locality but its edge tiles (1-2 taps per 32 KB of operand and output) are
     // bandwidth-bound and re-read the edge rows of the input: 545-570 / 650 / 2350 us, no better than image-major.
     int pm_nimg;
+    int xcd_order;            // pixel-major launches: tiles dealt to the XCDs in image-group-major runs (wstat_body)
 };
 
 struct RowInfo {
@@ -706,8 +707,35 @@ __device__ __forceinline__ void wstat_body(
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ra[kk] = *reinterpret_cast<const float4*>(p + 8 * kk);
     };
-    // one software pipeline over the workgroup's (tile, valid tap) steps; no block barrier inside
-    int tile = bid;
+    // Tile order.  Plain: tile = bid, bid + nblk, ...  Pixel-major launches (a tile = BMT images at ONE position, so
+    // the taps of neighbouring positions and of the other sub-pixel phases gather the same operand rows) deal the
+    // tiles in image-group-major order v = group * npix + position, one contiguous eighth of that order per XCD
+    // (workgroup ids go round the 8 XCDs; each XCD has its own 4 MB L2): the workgroups of an XCD then work, at any
+    // moment, on neighbouring positions of one image group — a working set of a few operand positions that its L2
+    // holds — instead of on one position of many groups, where every gathered row was an L2 miss.
+    const int gimg = PM ? g.pm_nimg / BMT : 0;                    // image groups
+    // (not for images of few positions: when the XCD's stride nblk / 8 is a multiple of the positions per image, a
+    // workgroup meets the same position in every group, and border positions have fewer taps than inner ones — the
+    // 16-position data gradient of layer 2 took 400 us instead of 310; rotating the positions per group cured that
+    // and cost the 49-position layers 10 %)
+    const bool swz = PM && g.xcd_order && gridDim.y == 1 && (nblk & 7) == 0 && ((stats_bid - bid) & 7) == 0 &&
+                     gimg > 0 && g.pm_nimg % BMT == 0 && ntiles % gimg == 0 && ntiles / gimg >= 32 &&
+                     (nblk >> 3) % (ntiles / gimg) != 0;
+    const int npos = swz ? ntiles / gimg : 1;
+    int v = bid, v_end = ntiles, v_step = nblk;
+    if (swz) {
+        const int x = bid & 7;
+        v = (int)((long)ntiles * x / 8) + (bid >> 3);
+        v_end = (int)((long)ntiles * (x + 1) / 8);
+        v_step = nblk >> 3;
+    }
+    auto tile_of = [&](int vv) {
+        if (vv >= v_end) return ntiles;                            // past the end: the loop stops, the decoders cope
+        if (!swz) return vv;
+        const int grp = vv / npos;
+        return (vv - grp * npos) * gimg + grp;
+    };
+    int tile = tile_of(v);
     TileInfo ti = taps.tile<PM>(g, lane, tile * BMT, BMT, tap0, ntaps);
     unsigned mask = ti.mask;
     int t = first_tap(mask);
@@ -731,7 +759,8 @@ __device__ __forceinline__ void wstat_body(
         int tn, ntile = tile;
         unsigned nmask = mask;
         if (last) {
-            ntile = tile + nblk;
+            v += v_step;
+            ntile = tile_of(v);
             ti = taps.tile<PM>(g, lane, ntile * BMT, BMT, tap0, ntaps);
             nmask = ti.mask;
             tn = first_tap(nmask);
@@ -1473,6 +1502,8 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
     // pixel-major only pays (and only keeps its tiles at one grid position) from a tile's worth of images on
     const int npix = c->Hg * c->Wg;
     g.pm_nimg = (c->pixel_major && npix > 0 && c->rows_total / npix >= 64) ? c->rows_total / npix : 0;
+    static const bool xcd_order = [] { const char* e = getenv("CMVAE_XCD_ORDER"); return !(e && e[0] == '0'); }();
+    g.xcd_order = xcd_order ? 1 : 0;
     for (int t = 0; t < 32; ++t) { g.dy[t] = c->dy[t]; g.dx[t] = c->dx[t]; g.a_col[t] = c->a_col[t]; g.w_off[t] = c->w_off[t]; }
     return g;
 }
@@ -1533,6 +1564,27 @@ extern "C" int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, co
         if (n > tiles) n = tiles;
         nb[k] = (int)n;
         used += nb[k];
+    }
+    // pixel-major launches: multiples of 8 workgroups per geometry, so that every geometry's workgroups spread evenly
+    // over the 8 XCDs (the tile order of wstat_body counts on it); what the rounding frees goes to the largest
+    if (p.g[0].pm_nimg > 0 && p.g[0].xcd_order) {
+        bool all8 = true;
+        for (int k = 0; k < ngeom; ++k) all8 = all8 && nb[k] >= 8;
+        if (all8) {
+            int freed = 0;
+            for (int k = 0; k < ngeom; ++k) { freed += nb[k] & 7; nb[k] &= ~7; }
+            for (int pass = 0; freed >= 8 && pass < 64; ++pass) {
+                int best = -1;
+                for (int k = 0; k < ngeom; ++k) {
+                    const long tiles = (p.g[k].rows_total + 127) / 128;
+                    if (nb[k] + 8 <= tiles && (best < 0 || work[k] * nb[best] > work[best] * nb[k])) best = k;
+                }
+                if (best < 0) break;
+                nb[best] += 8; freed -= 8;
+            }
+            used = 0;
+            for (int k = 0; k < ngeom; ++k) used += nb[k];
+        }
     }
     p.begin[0] = 0;
     for (int k = 0; k < 4; ++k) p.begin[k + 1] = p.begin[k] + nb[k];
