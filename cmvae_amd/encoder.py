@@ -4,7 +4,9 @@ x [n,784] -> Conv(1,64) -> BN -> ReLU -> MaxPool(ceil) -> 3 x [Conv(64,64) -> BN
 H [n,256] in channels-last order (column (i*2+j)*64 + c; the reference's column is c*4 + i*2+j — the
 consumer permutes its weight columns instead of the data).  BatchNorm statistics come from the conv
 epilogues, BatchNorm+ReLU is folded into the pooling kernel, and the backward pass recomputes the
-pooling argmax from the saved pre-BatchNorm activations.
+pooling argmax from the saved pre-BatchNorm activations.  Layer 1 in training keeps no activation at all: its
+pre-pooling output is recomputed from the images (nine multiply-adds per value) in the pooling pass and in a
+one-pass backward that gets the conv1 weight gradient by linearity.
 """
 import os
 
