@@ -353,13 +353,18 @@ def cpu_baseline_eval(cfg, threads, shots=(1, 5), calls=3, batch=None):
     return out
 
 
+# CMVAE_BENCH_REHEARSE=1: every rank on GPU 0, collectives over gloo (RCCL refuses two ranks on one device) — walks
+# the N > 1 code path of this file on a one-GPU box; the numbers of such a run mean nothing and the line says so
+REHEARSE = os.environ.get('CMVAE_BENCH_REHEARSE', '') == '1'
+
+
 # ----------------------------------------------------------------------------- self-launch
 def self_launch(args):
     """--gpus N > 1 without a torchrun environment: start N ranks in a fresh child before this process touches the
     GPU (never re-exec a process that has initialised it) and pass its output through."""
     import torch
     n_dev = torch.cuda.device_count()                       # does not initialise the GPU
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and not REHEARSE:
         print('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, n_dev), file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -370,6 +375,11 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1) // 2)))
+    if REHEARSE:
+        # two processes with several hardware queues each on ONE GPU dead-lock in the first collective that waits for
+        # the other rank's kernels (seen on the MI355X boxes of this project; with one queue per process, or with
+        # blocking launches, the same run completes): a property of sharing the device, not of the N-GPU job
+        env['GPU_MAX_HW_QUEUES'] = '1'
     return subprocess.call(cmd, env=env)
 
 
@@ -397,7 +407,11 @@ def main():
     import torch
     t_start = time.perf_counter()
     from cmvae_amd import dist as cdist
-    rank, world = cdist.init_from_env()
+    if REHEARSE:
+        os.environ['LOCAL_RANK'] = '0'
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get('CMVAE_BENCH_REHEARSE_LIMIT', '150')), exit=True)   # a rank that hangs says where
+    rank, world = cdist.init_from_env('gloo' if REHEARSE else None)
     if args.gpus != world:
         raise SystemExit('bench.py: --gpus %d but the job has %d ranks' % (args.gpus, world))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -436,7 +450,8 @@ def main():
     N = S * M
     out = {'metric': 'train episodes/sec (whole node) + eval EM episodes/sec, Omniglot 20-way', 'n_gpus': world,
            'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-           'dtype': 'f32', 'data': 'synthetic', 'rccl_ranks': ranks_seen,
+           'dtype': 'f32', 'data': 'synthetic' + (' (REHEARSAL: all ranks on one GPU over gloo)' if REHEARSE else ''),
+           'rccl_ranks': ranks_seen,
            'config': {'workload': cfg['workload'], 'name': args.config, 'global_batch_episodes': Bl * world,
                       'parallelism': 'dp%d' % world}}
     step = eager_step = None
