@@ -48,8 +48,11 @@ def _step(model, flat, opt, X, eps, idx, device):
 
 
 def _worker(rank, world, port, out):
+    # (one hardware queue per process: two processes with several queues each on ONE GPU can dead-lock in a collective
+    # that waits for the other rank's kernels — seen with bench.py's full-size rehearsal; set before the
+    # child's first HIP call)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0')
+                      LOCAL_RANK='0', GPU_MAX_HW_QUEUES='1')
     from cmvae_amd import dist as cdist
     from cmvae_amd.linear import FlatAdam
     cdist.init_from_env('gloo')
