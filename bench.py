@@ -410,7 +410,7 @@ def main():
     if REHEARSE:
         os.environ['LOCAL_RANK'] = '0'
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get('CMVAE_BENCH_REHEARSE_LIMIT', '150')), exit=True)   # a rank that hangs says where
+        faulthandler.dump_traceback_later(int(os.environ.get('CMVAE_BENCH_REHEARSE_LIMIT', '600')), exit=True)   # a rank that hangs says where
     rank, world = cdist.init_from_env('gloo' if REHEARSE else None)
     if args.gpus != world:
         raise SystemExit('bench.py: --gpus %d but the job has %d ranks' % (args.gpus, world))
@@ -584,6 +584,9 @@ def main():
                 out['cpu_baseline_eval'] = cpu_baseline_eval(cfg, threads)
         print(json.dumps(out), flush=True)
     barrier()
+    if REHEARSE:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
     if world > 1:
         torch.distributed.destroy_process_group()
 
