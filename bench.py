@@ -17,7 +17,10 @@ Workloads (BASELINE.json; --config):
   ce_sweep  CelebA 5-way evaluation sweep: NOTEARS-MLP causal layer, 4096 test episodes per shot in calls of 256
         episodes (semi-supervised EM batched over the call); `value` is eval episodes/s there.
 One "step" = forward + backward + gradient all-reduce + optimizer step over one synthetic meta-batch that is already
-resident in HBM.  Weak scaling: per-GPU work fixed.  Prints ONE JSON line on rank 0.
+resident in HBM.  --scaling weak (default): per-GPU work fixed (the config's episodes per GPU); --scaling strong
+--global-batch 32: a fixed global meta-batch split over the GPUs.  Prints ONE JSON line on rank 0; next to `value`
+it carries host_ms_per_step (the loop that issues the steps), the slowest / fastest rank's own step time and
+steps_long_ms (a second timed region of --long-steps steps).
 """
 import argparse
 import json
@@ -309,6 +312,17 @@ def _oracle(cfg, trainable):
     return OracleGMVAE(P, cfg['variant'], **okw, **kw), P
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline_train(cfg, threads, timed_steps=3):
     """The CPU oracle (a restatement of the reference's PyTorch op sequence) on the same training workload:
     1 warm-up step + `timed_steps` timed steps of one meta-batch."""
@@ -358,6 +372,32 @@ def cpu_baseline_eval(cfg, threads, shots=(1, 5), calls=3, batch=None):
 REHEARSE = os.environ.get('CMVAE_BENCH_REHEARSE', '') == '1'
 
 
+def dump_thread_states(path):
+    """Where every native thread of this process sleeps (name, state, kernel wait channel, pending system call) —
+    what faulthandler cannot see: the gloo / RCCL worker threads.  Reads /proc only."""
+    rows = []
+    base = '/proc/self/task'
+    for tid in sorted(os.listdir(base), key=int):
+        def rd(name):
+            try:
+                with open('%s/%s/%s' % (base, tid, name)) as f:
+                    return f.read().strip()
+            except OSError as e:
+                return '<%s>' % e.__class__.__name__
+        st = rd('stat')
+        state = st[st.rfind(')') + 2:].split(' ', 1)[0] if ')' in st else '?'
+        rows.append('tid %s comm=%s state=%s wchan=%s syscall=%s' % (tid, rd('comm'), state, rd('wchan'),
+                                                                    ' '.join(rd('syscall').split()[:4])))
+    with open(path, 'a') as f:
+        f.write('\n'.join(rows) + '\n')
+        f.flush()
+        try:                                   # last: a HIP call from here may block as well
+            import torch
+            f.write('default stream idle: %s\n' % torch.cuda.default_stream().query())
+        except Exception as e:                 # noqa: BLE001
+            f.write('stream query failed: %r\n' % (e,))
+
+
 # ----------------------------------------------------------------------------- self-launch
 def self_launch(args):
     """--gpus N > 1 without a torchrun environment: start N ranks in a fresh child before this process touches the
@@ -375,11 +415,8 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1) // 2)))
-    if REHEARSE:
-        # two processes with several hardware queues each on ONE GPU dead-lock in the first collective that waits for
-        # the other rank's kernels (seen on the MI355X boxes of this project; with one queue per process, or with
-        # blocking launches, the same run completes): a property of sharing the device, not of the N-GPU job
-        env['GPU_MAX_HW_QUEUES'] = '1'
+    if REHEARSE and os.environ.get('CMVAE_REHEARSE_HW_QUEUES'):
+        env['GPU_MAX_HW_QUEUES'] = os.environ['CMVAE_REHEARSE_HW_QUEUES']
     return subprocess.call(cmd, env=env)
 
 
@@ -392,6 +429,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph-step', choices=('auto', 'on', 'off'), default='auto',
                     help='training step replayed from a HIP graph (auto: feature configs on one GPU, as Trainer does)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: the config\'s episodes per GPU (4 for Omniglot, 16 for the feature models); strong: '
+                         '--global-batch episodes per step split over the GPUs (SURVEY.md §8d item 3)')
+    ap.add_argument('--global-batch', type=int, default=32, help='episodes per step of the whole job under --scaling strong')
+    ap.add_argument('--long-steps', type=int, default=500,
+                    help='a second, longer timed region after the K-step one (steps_long_ms in the line); 0 = off')
     ap.add_argument('--eval-calls', type=int, default=40)
     ap.add_argument('--eval-streams', type=int, default=8,
                     help='HIP streams the independent prediction calls are dealt to, as Trainer.eval does (1 = sequential)')
@@ -410,7 +453,16 @@ def main():
     if REHEARSE:
         os.environ['LOCAL_RANK'] = '0'
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get('CMVAE_BENCH_REHEARSE_LIMIT', '600')), exit=True)   # a rank that hangs says where
+        import threading
+        limit = int(os.environ.get('CMVAE_BENCH_REHEARSE_LIMIT', '600'))
+        faulthandler.dump_traceback_later(limit, exit=True)             # a rank that hangs says where
+        tdir = os.environ.get('CMVAE_DIST_TRACE', '')
+        if tdir:
+            os.makedirs(tdir, exist_ok=True)
+            wd = threading.Timer(max(1, limit - 5), dump_thread_states,
+                                 (os.path.join(tdir, 'threads_rank%s.txt' % os.environ.get('RANK', '0')),))
+            wd.daemon = True
+            wd.start()
     rank, world = cdist.init_from_env('gloo' if REHEARSE else None)
     if args.gpus != world:
         raise SystemExit('bench.py: --gpus %d but the job has %d ranks' % (args.gpus, world))
@@ -420,12 +472,17 @@ def main():
     ranks_seen = 1
     if world > 1:
         t = torch.ones(1, device=device)
-        torch.distributed.all_reduce(t)                      # the ranks RCCL actually connects
+        cdist.all_reduce(t, 'ranks_seen')                     # the ranks RCCL actually connects
         ranks_seen = int(t.item())
 
     way, S, M, Bl = cfg['way'], cfg['sample'], cfg['mc'], cfg['batch']
+    if args.scaling == 'strong':
+        if args.global_batch % world:
+            raise SystemExit('bench.py: --global-batch %d is not divisible by %d ranks' % (args.global_batch, world))
+        Bl = args.global_batch // world
     model = build_model(device, cfg)
-    flat = cdist.FlatGrads(model.parameters()).overlap_tail(model.tail_param_count())
+    n_tail = model.tail_param_count() if os.environ.get('CMVAE_OVERLAP_TAIL', '1') != '0' else 0
+    flat = cdist.FlatGrads(model.parameters()).overlap_tail(n_tail)
     from cmvae_amd.linear import FlatAdam
     opt = FlatAdam(flat, lr=cfg['lr'], weight_decay=5e-5)          # Adam as in omniglot/trainer.py:48-52
     np.random.seed(10086)
@@ -442,18 +499,19 @@ def main():
     def max_over_ranks(dt):
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            cdist.all_reduce(t, 'max_over_ranks', op=torch.distributed.ReduceOp.MAX)
             return float(t)
         return dt
 
     h_lambda, h_c, a_lambda = cfg['consts']
     N = S * M
     out = {'metric': 'train episodes/sec (whole node) + eval EM episodes/sec, Omniglot 20-way', 'n_gpus': world,
-           'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': args.scaling,
+           'vs_baseline': None,
            'dtype': 'f32', 'data': 'synthetic' + (' (REHEARSAL: all ranks on one GPU over gloo)' if REHEARSE else ''),
            'rccl_ranks': ranks_seen,
            'config': {'workload': cfg['workload'], 'name': args.config, 'global_batch_episodes': Bl * world,
-                      'parallelism': 'dp%d' % world}}
+                      'episodes_per_gpu': Bl, 'parallelism': 'dp%d' % world}}
     step = eager_step = None
     if not cfg.get('eval_only'):
         # synthetic meta-batches, resident in HBM before the timed region; each rank owns its shard
@@ -472,7 +530,7 @@ def main():
 
         def step(i):
             if graphed is not None:
-                idx = seeds.upload(cdist.draw_em_init(N, way, Bl * world, rank, world))
+                idx = seeds.upload(cdist.draw_em_init(N, way, Bl * world, rank, world, prefetch=True))
                 return graphed(pool[i % n_pool], idx, h_lambda, h_c, a_lambda)[:3]
             return eager_step(i)
 
@@ -480,7 +538,7 @@ def main():
             model.train()
             flat.zero()
             X = pool[i % n_pool]
-            idx = seeds.upload(cdist.draw_em_init(N, way, Bl * world, rank, world))
+            idx = seeds.upload(cdist.draw_em_init(N, way, Bl * world, rank, world, prefetch=True))
             eps = cdist.draw_eps(Bl * world, S, M, 64, device, rank, world) if world > 1 else None
             _, rec, kl, h_aug, _ = model(X, h_lambda, h_c, a_lambda, eps=eps, init_idx=idx)
             (rec + kl + h_aug).backward()
@@ -488,23 +546,49 @@ def main():
             opt.step()
             return rec, kl, h_aug
 
+        def min_over_ranks(dt):
+            if world > 1:
+                t = torch.tensor([dt], device=device, dtype=torch.float64)
+                cdist.all_reduce(t, 'min_over_ranks', op=torch.distributed.ReduceOp.MIN)
+                return float(t)
+            return dt
+
+        def timed(n_steps):
+            """n_steps steps between two barrier + synchronize pairs: (seconds max over ranks, min over ranks, host
+            seconds this rank spent issuing the steps, last losses)."""
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                last = step(i)
+            t_issued = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_rank = time.perf_counter() - t0          # this rank's own step time, before it waits for the others
+            barrier()
+            torch.cuda.synchronize()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            return dt, max_over_ranks(t_rank), min_over_ranks(t_rank), max_over_ranks(t_issued), last
+
         for i in range(args.warmup):
             step(i)
             torch.cuda.synchronize()
             note('warmup step %d done' % i)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            last = step(i)
-        barrier()
-        torch.cuda.synchronize()
-        dt = max_over_ranks(time.perf_counter() - t0)
-        losses = [float(x) for x in last]
+        dt, rank_max, rank_min, t_host, last = timed(args.steps)
+        losses = [float(x.detach()) for x in last]
         note('timed region done: %.2f ms/step' % (dt / args.steps * 1e3))
         out.update(value=round(Bl * world * args.steps / dt, 3), unit='train episodes/s',
                    ms_per_step=round(dt / args.steps * 1e3, 3),
+                   # host_ms_per_step: wall time of the loop that issues the steps, before any wait for the GPU (the
+                   # launches are asynchronous; a value near ms_per_step means the job is bound by the host)
+                   host_ms_per_step=round(t_host / args.steps * 1e3, 3),
+                   step_ms_rank_max=round(rank_max / args.steps * 1e3, 3),
+                   step_ms_rank_min=round(rank_min / args.steps * 1e3, 3),
                    final_losses={'rec': losses[0], 'kl': losses[1], 'h_aug': losses[2]})
+        if args.long_steps > args.steps and not REHEARSE:
+            dt_long = timed(args.long_steps)[0]
+            out['steps_long'] = args.long_steps
+            out['steps_long_ms'] = round(dt_long / args.long_steps * 1e3, 3)
+            note('long timed region done: %.2f ms/step over %d steps' % (out['steps_long_ms'], args.long_steps))
 
     # eval: GMVAE.prediction, query 15; the reference's episodes per call and 32 per call (what Trainer.eval uses
     # with --eval-batch-size 32); the sweep config runs 256 episodes per call over 4096 episodes
@@ -571,14 +655,17 @@ def main():
         out['roofline_other'] = em_roof
         note('roofline measurements done; starting cpu baseline')
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, int(os.environ.get('OMP_NUM_THREADS', '16')))
+            # the host's cores: every one of them unless the environment fixes the thread count (the GPU boxes of this
+            # project export OMP_NUM_THREADS = the CPU share of one GPU's slot; os.cpu_count() shows the whole machine)
+            threads = int(os.environ.get('OMP_NUM_THREADS') or 0) or (os.cpu_count() or 1)
+            host = {'cpu_model': cpu_model(), 'cpu_count': os.cpu_count(), 'threads': threads}
             if cfg.get('eval_only'):
                 cb = cpu_baseline_eval(cfg, threads, calls=2, batch=4)
-                out['cpu_baseline'] = dict(cb, value=cb['5shot'])
+                out['cpu_baseline'] = dict(cb, value=cb['5shot'], **host)
                 out['speedup_vs_cpu'] = round(out['value'] / cb['5shot'], 1)
             else:
                 cb = cpu_baseline_train(cfg, threads)
-                out['cpu_baseline'] = cb
+                out['cpu_baseline'] = dict(cb, **host)
                 out['speedup_vs_cpu'] = round(out['value'] / cb['value'], 1)
                 note('cpu train baseline done; starting cpu eval baseline')
                 out['cpu_baseline_eval'] = cpu_baseline_eval(cfg, threads)

@@ -154,6 +154,7 @@ SIGNATURES = {
                                     c_float, c_float, c_float, c_void_p]),
     'cmvae_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float,
                                 c_float, c_float, c_void_p]),
+    'cmvae_em_seed_draw_host': (c_int, [c_void_p, ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 

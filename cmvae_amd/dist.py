@@ -9,10 +9,65 @@ The reference has no distributed code; this module is new work.  Two exchange st
 Everything else on the path is per-episode and needs no collective.
 """
 import os
+import threading
+import time
 
 import numpy as np
 import torch
 import torch.distributed as tdist
+
+# CMVAE_DIST_TRACE=<dir>: every collective of this module is logged on issue and on completion (rank, host thread,
+# running number, what, elements) to <dir>/rank<r>.log — how a stalled multi-rank run says which exchange each rank
+# is in and which ones are still outstanding (DESIGN.md §5)
+_TRACE_DIR = os.environ.get('CMVAE_DIST_TRACE', '')
+_trace_lock = threading.Lock()
+_trace_seq = [0]
+_trace_file = [None]
+
+
+def trace(msg):
+    if not _TRACE_DIR:
+        return
+    with _trace_lock:
+        if _trace_file[0] is None:
+            os.makedirs(_TRACE_DIR, exist_ok=True)
+            _trace_file[0] = open(os.path.join(_TRACE_DIR, 'rank%d.log' % rank()), 'a')
+        _trace_file[0].write('%.6f [%s] %s\n' % (time.time(), threading.current_thread().name, msg))
+        _trace_file[0].flush()
+
+
+class _Done:
+    """Work handle of an exchange that already completed on the calling thread."""
+
+    def wait(self):
+        return True
+
+
+def _all_reduce(t, op, async_op):
+    if t.is_cuda and tdist.get_backend() == 'gloo':
+        # gloo has no GPU transport: c10d would stage the tensor through pinned memory on a pool stream and block one
+        # of its worker threads in hipStreamSynchronize.  Staging on the calling thread instead keeps it to ONE host
+        # thread per process that ever blocks on the GPU (tests and the one-GPU rehearsal of bench.py; DESIGN.md §5).
+        # The production backend is RCCL ("nccl"), which takes the tensor as it is.
+        h = t.detach().cpu()
+        tdist.all_reduce(h, op=op)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return tdist.all_reduce(t, op=op, async_op=async_op)
+
+
+def all_reduce(t, what, op=None, async_op=False):
+    """The one call site of torch.distributed.all_reduce on the path (traceable)."""
+    op = tdist.ReduceOp.SUM if op is None else op
+    if not _TRACE_DIR:
+        return _all_reduce(t, op, async_op)
+    with _trace_lock:
+        _trace_seq[0] += 1
+        n = _trace_seq[0]
+    trace('issue #%d %s numel=%d async=%s' % (n, what, t.numel(), async_op))
+    w = _all_reduce(t, op, async_op)
+    trace('%s #%d %s' % ('enqueued' if async_op else 'done', n, what))
+    return w
 
 
 def is_dist():
@@ -51,13 +106,95 @@ def shard_slice(n_global, r=None, ws=None):
     return slice(r * per, (r + 1) * per)
 
 
-def draw_em_init(n_samples, k, b_global, r=None, ws=None):
+def _draw_em_init_numpy(n_samples, k, b_global):
+    """The reference's own call sequence (omniglot/model.py:351-356) through the numpy interpreter path: what
+    SeedStream reproduces; kept as the checker of tests/test_seed_stream.py."""
+    return np.stack([np.random.choice(n_samples, k, replace=False) for _ in range(b_global)], 0).astype(np.int64)
+
+
+class SeedStream:
+    """EM seeds of the global meta-batch — one ``np.random.choice(N, K, replace=False)`` per episode in episode
+    order from numpy's GLOBAL generator, exactly as the reference draws them (omniglot/model.py:351-356) — taken
+    off the step's critical path.
+
+    Every rank draws the seeds of all `b_global` episodes and keeps its slice, so the numpy stream stays identical
+    to a single-process run; that is O(world size) serial host work per step (numpy: 0.23 ms per draw at N = 9600,
+    7.2 ms at 32 episodes, against a 12.5 ms GPU step plus the host's own launch work).  Two measures:
+      * the draw runs in the library (`cmvae_em_seed_draw_host`: numpy's legacy algorithm restated, bit-identical
+        indices and generator state, several times faster, no interpreter lock);
+      * `next(..., prefetch=True)` returns the seeds of this step and starts the draw of the NEXT step on a helper
+        thread.  The prefetched result is only used if numpy's global state is still the snapshot it was drawn
+        from when it is collected; any other consumer of the stream in between (evaluation episodes at an epoch
+        boundary, the data shuffle) simply voids it and the seeds are drawn again, in order, from the current
+        state.  The stream is therefore the sequential one in every interleaving."""
+
+    def __init__(self):
+        self._pool = None
+        self._pending = None
+
+    @staticmethod
+    def _state():
+        name, key, pos, has_gauss, cached = np.random.get_state(legacy=True)
+        if name != 'MT19937':
+            raise RuntimeError('cmvae_amd: numpy global generator is %s, expected MT19937' % name)
+        return np.ascontiguousarray(key, dtype=np.uint32).copy(), int(pos), has_gauss, cached
+
+    @staticmethod
+    def _run(key, pos, n_samples, k, b_global):
+        import ctypes
+        from ._lib import lib, check
+        out = np.empty((b_global, k), dtype=np.int64)
+        scratch = np.empty(n_samples, dtype=np.int64)
+        cpos = ctypes.c_int(pos)
+        check(lib.cmvae_em_seed_draw_host(key.ctypes.data, ctypes.byref(cpos), int(n_samples), int(k), int(b_global),
+                                          out.ctypes.data, scratch.ctypes.data), 'cmvae_em_seed_draw_host')
+        return out, key, cpos.value
+
+    def draw(self, n_samples, k, b_global):
+        """Synchronous draw: [b_global, k] int64, numpy's global state advanced as the reference's loop would."""
+        key, pos, has_gauss, cached = self._state()
+        out, key, pos = self._run(key, pos, n_samples, k, b_global)
+        np.random.set_state(('MT19937', key, pos, has_gauss, cached))
+        return out
+
+    def _prefetch(self, n_samples, k, b_global):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='cmvae_seeds')
+        key, pos, has_gauss, cached = self._state()
+        fut = self._pool.submit(self._run, key.copy(), pos, n_samples, k, b_global)
+        self._pending = ((n_samples, k, b_global), key, pos, has_gauss, cached, fut)
+
+    def next(self, n_samples, k, b_global, prefetch=False):
+        """Seeds of this step [b_global, k]; with `prefetch` the next step's draw (same shape) starts right away."""
+        out = None
+        if self._pending is not None:
+            shape, key0, pos0, has_gauss, cached, fut = self._pending
+            self._pending = None
+            res, key1, pos1 = fut.result()
+            key_now, pos_now, hg_now, _ = self._state()
+            if shape == (n_samples, k, b_global) and pos_now == pos0 and hg_now == has_gauss and \
+                    np.array_equal(key_now, key0):
+                np.random.set_state(('MT19937', key1, pos1, has_gauss, cached))
+                out = res
+        if out is None:
+            out = self.draw(n_samples, k, b_global)
+        if prefetch:
+            self._prefetch(n_samples, k, b_global)
+        return out
+
+
+_seed_stream = SeedStream()
+
+
+def draw_em_init(n_samples, k, b_global, r=None, ws=None, prefetch=False):
     """EM seeds for the global meta-batch, drawn exactly as the reference does — one
     ``np.random.choice(N, K, replace=False)`` per episode in episode order from numpy's global
     stream (omniglot/model.py:351-356) — on every rank, which then keeps its own slice.  The
-    numpy stream therefore stays identical to a single-process run."""
-    idx = np.stack([np.random.choice(n_samples, k, replace=False) for _ in range(b_global)], 0)
-    return idx[shard_slice(b_global, r, ws)].astype(np.int64)
+    numpy stream therefore stays identical to a single-process run.  `prefetch`: start the next step's draw on a
+    helper thread (SeedStream)."""
+    idx = _seed_stream.next(n_samples, k, b_global, prefetch=prefetch)
+    return np.ascontiguousarray(idx[shard_slice(b_global, r, ws)])
 
 
 def draw_eps(b_global, s, m, d, device, r=None, ws=None, dtype=torch.float32, generator=None):
@@ -100,8 +237,15 @@ def gather_episode_values(values, local_batch):
     The only collective of the evaluation loop."""
     if world_size() == 1:
         return values
-    parts = [torch.empty_like(values) for _ in range(world_size())]
-    tdist.all_gather(parts, values.contiguous())
+    values = values.contiguous()
+    if values.is_cuda and tdist.get_backend() == 'gloo':          # staged on the calling thread (see _all_reduce)
+        host = values.cpu()
+        parts = [torch.empty_like(host) for _ in range(world_size())]
+        tdist.all_gather(parts, host)
+        parts = [p.to(values.device) for p in parts]
+    else:
+        parts = [torch.empty_like(values) for _ in range(world_size())]
+        tdist.all_gather(parts, values)
     return torch.stack([p.view(-1, local_batch) for p in parts], 1).reshape(-1)
 
 
@@ -112,7 +256,7 @@ def global_sums(sums):
     (tests/sync_bn_reference.py) both call it."""
     if world_size() > 1:
         g = sums.clone()
-        tdist.all_reduce(g, op=tdist.ReduceOp.SUM)
+        all_reduce(g, 'bn_sums')
         return g
     return sums
 
@@ -163,9 +307,15 @@ class FlatGrads:
 
     def _tail_hook(self, _param):
         self._tail_pending -= 1
+        if self._tail_pending < 0:
+            # a second backward pass since zero(): the tail bucket already went out (and holds the ranks' sum), so
+            # this gradient would be accumulated into exchanged values and never be reduced itself
+            raise RuntimeError('cmvae_amd.FlatGrads: backward ran twice between zero() calls while the tail bucket is '
+                               'exchanged during the backward pass; call zero() before every backward, or '
+                               'overlap_tail(0) to accumulate gradients over several passes')
         if self._tail_pending == 0 and not self._tail_done:
             self._pack(self._tail_start, len(self.params))
-            self._tail_work = tdist.all_reduce(self.flat[self._tail_off:], op=tdist.ReduceOp.SUM, async_op=True)
+            self._tail_work = all_reduce(self.flat[self._tail_off:], 'grad_tail', async_op=True)
             self._tail_done = True
 
     def zero(self):
@@ -197,11 +347,13 @@ class FlatGrads:
             return
         if self._tail_done:
             self._pack(0, self._tail_start)
-            tdist.all_reduce(self.flat[:self._tail_off], op=tdist.ReduceOp.SUM)
+            all_reduce(self.flat[:self._tail_off], 'grad_head')
+            trace('wait grad_tail')
             self._tail_work.wait()               # stream-ordered on RCCL: the host does not block
+            trace('waited grad_tail')
             self._tail_work = None
         else:
             # no hook fired (overlap off, or a parameter of the tail got no gradient): one exchange of everything
             self.pack()
-            tdist.all_reduce(self.flat, op=tdist.ReduceOp.SUM)
+            all_reduce(self.flat, 'grad_all')
         self.flat.div_(ws)

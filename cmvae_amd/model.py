@@ -10,11 +10,11 @@ Where the arithmetic runs:
     nn.Linear (+ELU/ReLU), the bulk causal layer and Adam (cmvae_amd/linear.py): hand-written HIP
     kernels on the fp32-MFMA gather-GEMM family.
   * the 4-head softmax attention core of the two SABs: MFMA kernels (cmvae_amd/csrc/attention.hip).
-  * Still ATen on the GPU: tensor plumbing (cat, index gathers) and the scalar loss arithmetic.
+  * Still ATen on the GPU: tensor plumbing (cat, index gathers, weight layout permutations) and the final
+    `rec + kl + h_augment` add; the scalar tail of `forward` is two HIP kernels (ops.prior_logw, ops.elbo_tail).
 There is no CPU path: tensors must live on the GPU and the HIP library must be loadable.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -26,8 +26,6 @@ from .linear import linear, linear_mse
 from .decoder import decoder_bce, nhwc_perm, permute
 
 _LOG_NORM = -0.5 * np.log(2 * np.pi)
-# CMVAE_FUSED_TAIL=0: the scalar tail of forward as the chain of ATen kernels (A/B measurements)
-FUSED_TAIL = os.environ.get('CMVAE_FUSED_TAIL', '1') not in ('', '0')
 
 
 class _GMVAEBase(nn.Module):
@@ -134,31 +132,19 @@ class _GMVAEBase(nn.Module):
         pi_k, mu_k, trace_k, _ = self._unsup_prior(q_z, init_idx)
         # prior term with gradient to the causal parameters (mu_k, pi_k, trace_k are constants)
         q_eps_mu_k = self.causal(mu_k)
-        if extras is None and FUSED_TAIL and self.latent_size == 64:
-            # the scalar tail in five launches (forward + backward) instead of ~55 ATen ones
-            logw = ops.prior_logw(pi_k, trace_k, q_eps_mu_k)
-            log_p_z = ops.mixture_loglik(q_z, mu_k, logw)
-            h = self.h_a(A)
-            kl_loss, h_augment = ops.elbo_tail(q_z4_logq, log_p_z, q_eps, h, A, h_lambda, h_c, a_lambda)
-            return kl_loss, h_augment, h
-        logw = torch.log(pi_k) + self.gaussian_log_prob(
-            q_eps_mu_k, torch.log(trace_k)[:, :, None].expand(-1, -1, self.latent_size))
-        log_p_z = ops.mixture_loglik(q_z, mu_k, logw)                      # [B, N]
-        log_q_z = q_z4_logq                                                # [B, S, M]
-        if extras is None:
-            # mean over rows of glp(q_eps, 0) = -0.5 * sum(q_eps^2) / rows + D*c: one reduction instead of four passes
-            log_p_eps = None
-            log_p_eps_mean = -0.5 * torch.linalg.vector_norm(q_eps).pow(2) / (q_eps.numel() // self.latent_size) \
-                + self.latent_size * _LOG_NORM
-        else:
-            log_p_eps = (-0.5 * q_eps.pow(2) + self.log_norm_constant).sum(-1)  # glp(q_eps, 0)
-            log_p_eps_mean = log_p_eps.mean()
-        kl_loss = log_q_z.mean() - log_p_z.mean() - log_p_eps_mean
+        # the scalar tail in five launches (forward + backward): prior log-weights, mixture log-likelihood, and
+        # the three KL means + h_augment (ops.prior_logw, ops.mixture_loglik, ops.elbo_tail)
+        logw = ops.prior_logw(pi_k, trace_k, q_eps_mu_k)
+        log_p_z = ops.mixture_loglik(q_z, mu_k, logw)
         h = self.h_a(A)
-        h_augment = h_lambda * h + 0.5 * h_c * h * h + a_lambda * A.abs().sum()
+        kl_loss, h_augment = ops.elbo_tail(q_z4_logq, log_p_z, q_eps, h, A, h_lambda, h_c, a_lambda)
         if extras is not None:
+            # exports for the parity tests: what the step computed, plus glp(q_eps, 0) per row, which the fused tail
+            # only holds as a sum (computed here on the side, outside the graph); extras never selects arithmetic
+            with torch.no_grad():
+                log_p_eps = (-0.5 * q_eps.detach().pow(2) + self.log_norm_constant).sum(-1)
             extras.update(pi_k=pi_k, mu_k=mu_k, trace_k=trace_k, log_p_z=log_p_z.view(B, -1),
-                          log_q_z=log_q_z, log_p_eps=log_p_eps, q_z=q_z, q_eps=q_eps, A=A)
+                          log_q_z=q_z4_logq, log_p_eps=log_p_eps, q_z=q_z, q_eps=q_eps, A=A)
         return kl_loss, h_augment, h
 
     def _tr_predict_from_posterior(self, q_mean, q_logvar, eps, init_idx):

@@ -93,14 +93,17 @@ class Trainer(object):
                 f.write(json.dumps(rec) + '\n')
 
     # ------------------------------------------------------------------ one training step
-    def train_step(self, h_lambda, h_c, a_lambda):
+    def train_step(self, h_lambda, h_c, a_lambda, prefetch_seeds=False):
+        """One step.  `prefetch_seeds`: start drawing the NEXT step's EM seeds on a helper thread (dist.SeedStream;
+        the caller says so when another training step follows — a wrong guess only wastes the draw)."""
         a = self.args
         self.model.train()
         self.flat.zero()
         X = self.stream.next()                                         # the global meta-batch, same on every rank
         shape = self.input_shape if isinstance(self.input_shape, list) else [self.input_shape]
         X = X.view(a.batch_size, a.sample_size, *shape)[cdist.shard_slice(a.batch_size, self.rank, self.world)]
-        idx = cdist.draw_em_init(a.sample_size * a.train_mc_sample_size, a.way, a.batch_size, self.rank, self.world)
+        idx = cdist.draw_em_init(a.sample_size * a.train_mc_sample_size, a.way, a.batch_size, self.rank, self.world,
+                                 prefetch=prefetch_seeds)
         idx = self.seeds.upload(idx)
         eps = None
         if self.world > 1:
@@ -134,8 +137,10 @@ class Trainer(object):
         while global_epoch * a.freq_iters < a.train_iters:
             t0 = time.perf_counter()
             steps = 0
-            for _ in range(a.freq_iters):
-                rec_loss, kl_loss, h_augment, h = self.train_step(h_lambda, h_c, a_lambda)
+            for it in range(a.freq_iters):
+                # the evaluation after the last step of an epoch draws its episodes from the same numpy stream
+                more = it + 1 < a.freq_iters and not a.debug
+                rec_loss, kl_loss, h_augment, h = self.train_step(h_lambda, h_c, a_lambda, prefetch_seeds=more)
                 global_step += 1
                 steps += 1
                 if global_step % self.log_interval == 0 or a.debug:

@@ -45,3 +45,24 @@ def test_main_routes_multi_gpu_requests_to_the_launcher(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 17
+
+
+def test_strong_scaling_flags_reach_the_ranks(monkeypatch):
+    """--scaling strong --global-batch 32 is part of the command line every rank re-parses."""
+    import torch
+    import bench
+    calls = {}
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: calls.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--scaling', 'strong', '--global-batch', '32'])
+    assert bench.self_launch(types.SimpleNamespace(gpus=8)) == 0
+    assert calls['cmd'][-6:] == ['--gpus', '8', '--scaling', 'strong', '--global-batch', '32']
+    assert 'GPU_MAX_HW_QUEUES' not in calls['env'] or calls['env']['GPU_MAX_HW_QUEUES'] == os.environ.get('GPU_MAX_HW_QUEUES')
+
+
+def test_rank_count_mismatch_is_refused(monkeypatch):
+    import bench
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '3', '--scaling', 'strong', '--global-batch', '32'])
+    with pytest.raises(SystemExit):
+        bench.main()                     # 3 ranks requested in a 1-rank job: refused before anything is built

@@ -60,6 +60,17 @@ def _worker(rank, world, port, out):
     loss = (net(x) ** 2).mean()
     loss.backward()
     flat.allreduce()
+    grad_full, rm_full, rv_full = flat.flat.clone(), net[1].running_mean.clone(), net[4].running_var.clone()
+    # a second backward between two zero() calls would add into the tail bucket that already went out: refused
+    flat.zero()
+    (net(x) ** 2).mean().backward()
+    try:
+        (net(x) ** 2).mean().backward()
+        second_backward_refused = False
+    except RuntimeError as e:
+        second_backward_refused = 'backward ran twice' in str(e)
+    flat.allreduce()                              # consumes the outstanding tail exchange on both ranks
+    assert second_backward_refused
     np.random.seed(77)
     idx = cdist.draw_em_init(50, 3, 8)
     # reparametrisation noise: same generator state on both ranks -> disjoint slices of the single-process draw
@@ -69,8 +80,8 @@ def _worker(rank, world, port, out):
     mine = torch.tensor([4.0 * t + 2 * rank + j for t in range(3) for j in range(2)])
     gathered = cdist.gather_episode_values(mine, 2)
     assert gathered.tolist() == [float(i) for i in range(12)], gathered
-    out[rank] = dict(y=y.detach(), grad=flat.flat.clone(), rm=net[1].running_mean.clone(),
-                     rv=net[4].running_var.clone(), idx=idx, after=np.random.rand(), eps=eps.clone(),
+    out[rank] = dict(y=y.detach(), grad=grad_full, rm=rm_full,
+                     rv=rv_full, idx=idx, after=np.random.rand(), eps=eps.clone(),
                      g_partial=g_partial)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -89,7 +100,7 @@ def test_two_rank_step_equals_single_process():
     (net[0](_data()) ** 2).mean().backward()
     flat.pack()
     g_partial = flat.flat.clone()
-    for _ in range(2):                                 # the workers ran two full training-mode forwards
+    for _ in range(2):                                 # the workers' first two full training-mode forwards
         flat.zero()
         y = net(_data())
         (y ** 2).mean().backward()

@@ -1,8 +1,13 @@
 """Episode-sharded data parallelism on the real kernels: two ranks share the one GPU of the test box and talk over
 gloo (RCCL refuses two ranks on one device; the collectives' call sites are the same).  A step on the sharded
 meta-batch must equal the single-process step on the whole meta-batch: BatchNorm statistics span all episodes
-(collective C2 inside the HIP encoder / decoder pipelines), gradients are averaged (C1), EM seeds come from the shared
-numpy stream."""
+(collective C2 inside the HIP encoder / decoder pipelines; whole-meta-batch BatchNorm as in omniglot/module.py:15-31,
+51-59), gradients are averaged (C1), EM seeds come from the shared numpy stream.
+
+Two shapes: a tiny one (48 decoder images per rank: the LDS-staged weight gradient) and the shape the 8-GPU job runs
+per rank — 4 episodes x 300 items x 32 MC samples, 20-way, 10 EM iterations — against one process on all 8 episodes:
+streaming weight gradient, split sixteen-tap data gradient with the BatchNorm-backward sums in its epilogue feeding
+`dist.global_sums`, and the two-launch BatchNorm finalize that replaces `cmvae_bn_finalize_part` when world > 1."""
 import os
 import socket
 
@@ -12,7 +17,7 @@ import torch
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
-B, S, K, M = 2, 12, 3, 4
+SHAPES = {'tiny': dict(B=2, S=12, K=3, M=4, iters=3), 'o20_per_rank': dict(B=8, S=300, K=20, M=32, iters=10)}
 
 
 def _free_port():
@@ -23,18 +28,23 @@ def _free_port():
     return p
 
 
-def _build(device):
+def _build(device, sh):
     from cmvae_amd.model import OmniglotGMVAE
     torch.manual_seed(4)
-    return OmniglotGMVAE(component_size=K, train_mc_sample_size=M, test_mc_sample_size=M, unsupervised_em_iters=3,
-                         semisupervised_em_iters=3).to(device).train()
+    return OmniglotGMVAE(component_size=sh['K'], train_mc_sample_size=sh['M'], test_mc_sample_size=sh['M'],
+                         unsupervised_em_iters=sh['iters'], semisupervised_em_iters=sh['iters']).to(device).train()
 
 
-def _inputs():
+def _inputs(sh):
     g = torch.Generator().manual_seed(5)
-    X = (torch.rand(B, S, 1, 28, 28, generator=g) < 0.15).float()
-    eps = torch.randn(B, S, M, 64, generator=g)
+    X = (torch.rand(sh['B'], sh['S'], 1, 28, 28, generator=g) < 0.15).float()
+    eps = torch.randn(sh['B'], sh['S'], sh['M'], 64, generator=g)
     return X, eps
+
+
+def _bn_stats(model):
+    return torch.cat([b.detach().reshape(-1).float().cpu() for n, b in model.named_buffers()
+                      if n.endswith('running_mean') or n.endswith('running_var')])
 
 
 def _step(model, flat, opt, X, eps, idx, device):
@@ -47,44 +57,45 @@ def _step(model, flat, opt, X, eps, idx, device):
     return torch.stack([rec.detach(), kl.detach(), h_aug.detach()]).cpu(), grads.cpu()
 
 
-def _worker(rank, world, port, out):
-    # (one hardware queue per process: two processes with several queues each on ONE GPU can dead-lock in a collective
-    # that waits for the other rank's kernels — seen with bench.py's full-size rehearsal; set before the
-    # child's first HIP call)
+def _worker(rank, world, port, out, shape):
+    # default hardware queues: the exchanges of GPU tensors over gloo are staged on the calling thread
+    # (cmvae_amd/dist.py: _all_reduce; DESIGN.md §5 has the story of the stall this replaced)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', GPU_MAX_HW_QUEUES='1')
+                      LOCAL_RANK='0')
+    sh = SHAPES[shape]
     from cmvae_amd import dist as cdist
     from cmvae_amd.linear import FlatAdam
     cdist.init_from_env('gloo')
     device = torch.device('cuda:0')
-    model = _build(device)
+    model = _build(device, sh)
     flat = cdist.FlatGrads(model.parameters()).overlap_tail(model.tail_param_count())    # decoder + proj bucket
     opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
-    X, eps = _inputs()
-    sl = cdist.shard_slice(B)
+    X, eps = _inputs(sh)
+    sl = cdist.shard_slice(sh['B'])
     np.random.seed(21)
-    idx = cdist.draw_em_init(S * M, K, B)
+    idx = cdist.draw_em_init(sh['S'] * sh['M'], sh['K'], sh['B'])
     losses, grads = _step(model, flat, opt, X[sl], eps[sl], idx, device)
     assert flat._tail_off < flat.flat.numel()          # the tail bucket exists; _step's allreduce consumed it
-    out[rank] = dict(losses=losses, grads=grads, w=model.proj[0].weight.detach().cpu().clone(),
-                     rm=model.decoder.decoder[1].running_mean.detach().cpu().clone())
+    out[rank] = dict(losses=losses, grads=grads, w=model.proj[0].weight.detach().cpu().clone(), bn=_bn_stats(model))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_on_hip_kernels_equal_one_process(device):
+@pytest.mark.parametrize('shape', ['tiny', 'o20_per_rank'])
+def test_two_ranks_on_hip_kernels_equal_one_process(device, shape):
+    sh = SHAPES[shape]
     world, port = 2, _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, shape), nprocs=world, join=True)
     from cmvae_amd import dist as cdist
     from cmvae_amd.linear import FlatAdam
-    model = _build(device)
+    model = _build(device, sh)
     flat = cdist.FlatGrads(model.parameters())
     opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
-    X, eps = _inputs()
+    X, eps = _inputs(sh)
     np.random.seed(21)
-    idx = np.stack([np.random.choice(S * M, K, replace=False) for _ in range(B)], 0).astype(np.int64)
+    idx = cdist._draw_em_init_numpy(sh['S'] * sh['M'], sh['K'], sh['B'])     # the reference's own numpy calls
     losses, grads = _step(model, flat, opt, X, eps, idx, device)
     # every loss term is a mean over equal-sized shards (h_augment is replicated)
     mean_losses = (out[0]['losses'] + out[1]['losses']) / 2
@@ -95,10 +106,15 @@ def test_two_ranks_on_hip_kernels_equal_one_process(device):
     gw = flat.views[[id(p) for p in flat.params].index(id(model.proj[0].weight))].detach().cpu()
     solid = gw.abs() > 1e-5 * scale
     assert float(solid.float().mean()) > 0.5
+    bn = _bn_stats(model)
     for r in range(world):
-        assert float((out[r]['grads'] - grads).abs().max()) < 2e-4 * scale
+        err = float((out[r]['grads'] - grads).abs().max())
+        print('  %s rank %d: max |grad - single| %.2e of scale %.2e; BatchNorm running statistics %.2e'
+              % (shape, r, err, scale, float((out[r]['bn'] - bn).abs().max())))
+        assert err < 2e-4 * scale
         dw = (out[r]['w'] - model.proj[0].weight.detach().cpu()).abs()
         assert float(dw[solid].max()) < 1e-5 and float(dw.max()) < 2.1e-3      # never more than two steps of lr
-        assert torch.allclose(out[r]['rm'], model.decoder.decoder[1].running_mean.detach().cpu(), atol=1e-6)
+        assert torch.allclose(out[r]['bn'], bn, atol=1e-6, rtol=1e-6)           # all 14 running_mean / running_var
     assert torch.equal(out[0]['grads'], out[1]['grads'])
     assert torch.equal(out[0]['w'], out[1]['w'])                            # the ranks stay in lock step
+    assert torch.equal(out[0]['bn'], out[1]['bn'])

@@ -9,8 +9,10 @@
     NOTEARS-MLP causal layer (celeba/model.py:22, mimgnet/model.py:442-511).
 
 Both sides get identical weights, inputs, reparametrisation noise and EM seeds.  Tolerance: 1e-4 relative on ELBO
-terms and EM parameters (north_star), 2e-4 on per-tensor gradients (norm-wise, against the fp32 oracle), labels
-bit-exact.  The measured errors are printed (run with -s to see them)."""
+terms and EM parameters (north_star), 5e-5 on per-tensor gradients (norm-wise, against the fp32 oracle; a tensor
+whose fp32 oracle gradient is itself further than that from the float64 oracle's must be as close to float64 as the
+fp32 oracle is), labels bit-exact.  The model is called exactly as bench.py and Trainer call it (`extras=` only exports tensors; it selects no
+arithmetic), so the step under test is the fused-tail step that ships.  The measured errors are printed (run with -s to see them)."""
 import numpy as np
 import pytest
 import torch
@@ -18,7 +20,7 @@ import torch
 from tests.helpers import build_pair, omniglot_batch, feature_batch, rel_err, em_elementwise_check, RTOL
 
 pytestmark = pytest.mark.gpu
-GTOL = 2e-4
+GTOL = 5e-5          # per-tensor gradient bar, norm-wise against the fp32 oracle (measured worst: 6e-6)
 
 
 def _scalar_close(name, a, b, tol=RTOL, floor=1e-7):
@@ -44,6 +46,21 @@ def _train_step_pair(variant, linear, B, S, M, K, iters, device, al, feat=256, s
                   extras=ex_g)
     (out_g[1] + out_g[2] + out_g[3]).backward()
     torch.cuda.synchronize()
+
+    def grads_fp64():
+        """The same step of the oracle in float64: how far fp32 rounding alone moves a gradient of this problem.
+        Only run when a tensor misses the bar against the fp32 oracle."""
+        from oracle.gmvae_oracle import OracleGMVAE
+        P64 = make_trainable({k: (v.detach().double() if v.is_floating_point() else v) for k, v in oracle.P.items()})
+        o64 = OracleGMVAE(P64, oracle.variant, input_shape=oracle.input_shape, unsupervised_em_iters=oracle.unsup_iters,
+                          semisupervised_em_iters=oracle.semi_iters, fix_pi=oracle.fix_pi, component_size=oracle.K,
+                          train_mc_sample_size=oracle.train_mc, test_mc_sample_size=oracle.test_mc,
+                          linear=oracle.linear)
+        out64 = o64.forward(X.double(), 0.1, 0.1, al, eps=eps.double(), init_idx=idx)
+        (out64[1] + out64[2] + out64[3]).backward()
+        return {k: v.grad for k, v in P64.items() if getattr(v, 'grad', None) is not None}
+
+    ex_o['grads_fp64'] = grads_fp64
     return model, oracle, out_o, ex_o, out_g, ex_g
 
 
@@ -67,24 +84,44 @@ def _check_step(model, oracle, out_o, ex_o, out_g, ex_g):
     grads = {n: oracle.P[n].grad for n, _ in model.named_parameters() if oracle.P[n].grad is not None}
     gscale = max(float(g.abs().max()) for g in grads.values())
     worst = ('', 0.0)
+    g64 = None
     for name, p in model.named_parameters():
         g_o = oracle.P[name].grad
         if g_o is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
-        err = float((p.grad.detach().cpu().double() - g_o.double()).norm())
+        g_h = p.grad.detach().cpu().double()
+        err = float((g_h - g_o.double()).norm())
         nrm = float(g_o.double().norm())
         floor = 1e-6 * gscale * np.sqrt(g_o.numel())
         r = max(err - floor, 0.0) / max(nrm, 1e-30)
         if r > worst[1]:
             worst = (name, r)
-        assert err <= GTOL * nrm + floor, '%s: gradient error %.3e of norm %.3e' % (name, err, nrm)
+        if err <= GTOL * nrm + floor:
+            continue
+        # a sum of many cancelling terms (a weight gradient that is small against its summands): the fp32 oracle
+        # itself sits that far from the exact gradient.  Then the HIP gradient must be as close to the float64
+        # result as the fp32 oracle is (x2), and still within 4 GTOL of the fp32 oracle.
+        if g64 is None:
+            g64 = ex_o['grads_fp64']()
+        err64 = float((g_h - g64[name]).norm())
+        ref64 = float((g_o.double() - g64[name]).norm())
+        print('  %s: |hip - oracle32| %.2e  |hip - oracle64| %.2e  |oracle32 - oracle64| %.2e  norm %.2e'
+              % (name, err, err64, ref64, nrm))
+        assert err64 <= 2 * ref64 + floor and err <= 4 * GTOL * nrm + floor, \
+            '%s: gradient error %.3e of norm %.3e (fp64: hip %.3e, oracle32 %.3e)' % (name, err, nrm, err64, ref64)
     print('  worst gradient: %s %.2e' % worst)
 
 
 def test_omniglot_20way_training_step_against_oracle(device):
     """The metric's own configuration, one whole step, forward and backward."""
     res = _train_step_pair('omniglot', False, 4, 300, 32, 20, 10, device, al=1e-4)
+    _check_step(*res)
+
+
+def test_omniglot_5way_training_step_against_oracle(device):
+    """BASELINE.json configs[1]: Omniglot 5-way, sample-size 200 (B=4, S=200, M=32, K=5)."""
+    res = _train_step_pair('omniglot', False, 4, 200, 32, 5, 10, device, al=1e-4)
     _check_step(*res)
 
 
