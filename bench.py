@@ -521,11 +521,13 @@ def main():
         seeds = cdist.SeedUploader((Bl, way), device)
 
         # what Trainer does (--graph-step auto): the feature models' step, bound by the host's launch rate when issued
-        # eagerly, is replayed from a HIP graph in a single process; the Omniglot step stays eager
+        # eagerly, is replayed from a HIP graph (with several ranks: up to the gradient pack); the Omniglot step
+        # stays eager
         graphed = None
-        if args.graph_step == 'on' or (args.graph_step == 'auto' and cfg['variant'] != 'omniglot' and world == 1):
+        if (args.graph_step == 'on' and (world == 1 or cfg['variant'] != 'omniglot')) or \
+                (args.graph_step == 'auto' and cfg['variant'] != 'omniglot'):
             from cmvae_amd.graph_step import GraphedStep
-            graphed = GraphedStep(model, flat, opt) if world == 1 else None
+            graphed = GraphedStep(model, flat, opt)      # several ranks: the exchange and Adam follow the replay
         out['config']['graph_step'] = graphed is not None
 
         def step(i):

@@ -9,6 +9,7 @@ import functools
 
 import torch
 
+from . import _workspace
 from ._lib import lib, check, ConvGeom
 
 _p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
@@ -140,18 +141,8 @@ def conv_gemm_multi(geoms, A, Wt, out, bias=None, a_scale=None, a_shift=None, st
     return part
 
 
-_ws_cache = {}
-
-
 def _wgrad_ws(rows, device):
-    nbytes = lib.cmvae_conv_wgrad_workspace_bytes(rows)
-    # one workspace per (device, stream): launches on different streams may be in flight together
-    key = (device, 'wgrad', _stream())
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+    return _workspace.get(lib.cmvae_conv_wgrad_workspace_bytes(rows), device, 'conv_wgrad')
 
 
 def conv_wgrad(g, A, G, dW, tap_off, s_ci, s_co, db=None, accumulate_db=False, a_scale=None, a_shift=None,

@@ -339,6 +339,14 @@ class FlatGrads:
     def pack(self):
         self._pack(0, len(self.params))
 
+    def exchange(self):
+        """Mean over ranks of the packed buffer, one all-reduce of everything (for callers that pack elsewhere — the
+        HIP-graph step packs inside the graph and exchanges after the replay)."""
+        ws = world_size()
+        if ws > 1:
+            all_reduce(self.flat, 'grad_all')
+            self.flat.div_(ws)
+
     def allreduce(self):
         """Gather the gradients, then mean over ranks (every loss term is a mean over equal-sized shards)."""
         ws = world_size()
@@ -352,8 +360,8 @@ class FlatGrads:
             self._tail_work.wait()               # stream-ordered on RCCL: the host does not block
             trace('waited grad_tail')
             self._tail_work = None
+            self.flat.div_(ws)
         else:
             # no hook fired (overlap off, or a parameter of the tail got no gradient): one exchange of everything
             self.pack()
-            all_reduce(self.flat, 'grad_all')
-        self.flat.div_(ws)
+            self.exchange()

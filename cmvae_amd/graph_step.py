@@ -8,11 +8,17 @@ feature variants (`--graph-step auto`).
 
 What makes the step replayable: inputs, EM seeds and the reparametrisation noise live in static buffers that are
 refilled before every replay (the noise by the same `torch.randn` call, in the same generator order, as the eager
-step draws it: same realisation); the loss constants are frozen into the graph (one graph per (h_lambda, h_c, a_lambda));
-Adam reads its step count from device memory (`FlatAdam.device_step`, `cmvae_adam_step_dev`).  Single process only: with
-several ranks the gradient exchange stays eager and so does the step.
+step draws it: same realisation); the loss constants are frozen into the graph, so a change of (h_lambda, h_c,
+a_lambda) — `--dual-ascent` moves them once per epoch — drops the graph of that shape and captures a new one (one
+graph per shape at any time: a graph's private pool holds a whole step of activations);
+Adam reads its step count from device memory (`FlatAdam.device_step`, `cmvae_adam_step_dev`).  With several ranks the
+graph ends after the gradient pack: the all-reduce (one bucket; the early tail bucket is switched off, a collective
+cannot be issued from a hook inside a capture) and the Adam launch follow every replay eagerly, and the noise buffer
+takes this rank's slice of the global draw (`dist.draw_eps`), as the eager sharded step does.
 """
 import torch
+
+from . import dist as cdist
 
 
 class GraphedStep:
@@ -24,17 +30,36 @@ class GraphedStep:
         if self.device.type != 'cuda':
             raise RuntimeError('cmvae_amd: GraphedStep needs the model on the GPU (there is no CPU path)')
         optimizer.device_step()
+        self.world, self.rank = cdist.world_size(), cdist.rank()
+        if self.world > 1:
+            flat.overlap_tail(0)
         self.calls = 0
-        self.graphs = {}            # (consts, shapes) -> (graph, X, idx, eps, outputs)
+        self.graphs = {}            # shapes -> (consts, graph, X, idx, eps, outputs)
 
     def _body(self, X, idx, eps, consts):
         self.model.train()
         self.flat.zero()
         _, rec, kl, h_aug, h = self.model(X, *consts, eps=eps, init_idx=idx)
         (rec + kl + h_aug).backward()
-        self.flat.allreduce()
-        self.optimizer.step()
+        self.flat.pack()
+        if self.world == 1:
+            self.optimizer.step()
         return rec.detach(), kl.detach(), h_aug.detach(), h.detach()
+
+    def _after(self):
+        """What follows the graph when the job has several ranks: gradient exchange and update."""
+        if self.world > 1:
+            self.flat.exchange()
+            self.optimizer.step()
+
+    def _draw(self, shape, out=None):
+        """The step's reparametrisation noise, by the same generator calls as the eager step."""
+        if self.world == 1:
+            if out is None:
+                return torch.randn(shape, device=self.device, dtype=torch.float32)
+            return torch.randn(shape, out=out)
+        eps = cdist.draw_eps(shape[0] * self.world, shape[1], shape[2], shape[3], self.device, self.rank, self.world)
+        return eps if out is None else out.copy_(eps)
 
     def _eps_shape(self, X):
         m = self.model
@@ -46,20 +71,27 @@ class GraphedStep:
         consts = (float(h_lambda), float(h_c), float(a_lambda))
         self.calls += 1
         if self.calls <= self.WARMUP:
-            eps = torch.randn(self._eps_shape(X), device=self.device, dtype=torch.float32)
-            return self._body(X, idx, eps, consts)
-        key = (consts, tuple(X.shape), tuple(idx.shape), X.dtype)
+            out = self._body(X, idx, self._draw(self._eps_shape(X)), consts)
+            self._after()
+            return out
+        key = (tuple(X.shape), tuple(idx.shape), X.dtype)
         entry = self.graphs.get(key)
+        if entry is not None and entry[0] != consts:
+            # new loss constants: the old graph (and the step of activations in its pool) goes before the new capture
+            del self.graphs[key]
+            entry[1].reset()
+            entry = None
         if entry is None:
             sX, sidx = X.clone(), idx.clone()
             seps = torch.zeros(self._eps_shape(X), device=self.device, dtype=torch.float32)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):           # records only: no weight is touched until the replay below
                 out = self._body(sX, sidx, seps, consts)
-            entry = self.graphs[key] = (graph, sX, sidx, seps, out)
-        graph, sX, sidx, seps, out = entry
+            entry = self.graphs[key] = (consts, graph, sX, sidx, seps, out)
+        _, graph, sX, sidx, seps, out = entry
         sX.copy_(X, non_blocking=True)
         sidx.copy_(idx, non_blocking=True)
-        torch.randn(seps.shape, out=seps)
+        self._draw(tuple(seps.shape), out=seps)
         graph.replay()
+        self._after()
         return out

@@ -10,6 +10,7 @@
 """
 import torch
 
+from . import _workspace
 from ._lib import lib, check
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'elu': 2}
@@ -25,16 +26,7 @@ def _need(t, name):
         raise RuntimeError('cmvae_amd.linear: %s must be a float32 GPU tensor (there is no CPU path)' % name)
 
 
-_ws = {}
 TAPS = None          # tests set this to a dict: receives the output of every Linear+ReLU of a forward, in call order
-
-
-def _workspace(nbytes, device):
-    ws = _ws.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws[device] = ws
-    return ws
 
 
 def linear_fwd(x2, weight, bias, act, out=None):
@@ -59,7 +51,7 @@ def linear_bwd(x2, weight, dz, need_dx, need_db):
     dW = torch.empty_like(weight)
     db = torch.empty(out_f, device=x2.device, dtype=torch.float32) if need_db else None
     nbytes = lib.cmvae_linear_bwd_workspace_bytes(rows, in_f, out_f)
-    ws = _workspace(nbytes, x2.device)
+    ws = _workspace.get(nbytes, x2.device, 'linear_bwd')
     check(lib.cmvae_linear_bwd(_p(x2), x2.stride(0), _p(weight), _p(dz), dz.stride(0), rows, in_f, out_f, _p(dx),
                                in_f, _p(dW), _p(db), _p(ws), ws.numel(), _stream()), 'cmvae_linear_bwd')
     return dx, dW, db

@@ -71,6 +71,7 @@ class Trainer(object):
         self.optimizer = FlatAdam(self.flat, lr=args.lr, weight_decay=args.weight_decay)
         self.seeds = cdist.SeedUploader((self.local_batch, args.way), self.device)
         self._graphed = None
+        self._pipe = None                        # the evaluation pipeline (streams + captured graphs), built once
         self.log_interval = max(1, int(getattr(args, 'log_interval', 50)))
         self.best_files = {}
         self.log_path = os.path.join(args.save_dir, 'train_log.jsonl')
@@ -105,15 +106,15 @@ class Trainer(object):
         idx = cdist.draw_em_init(a.sample_size * a.train_mc_sample_size, a.way, a.batch_size, self.rank, self.world,
                                  prefetch=prefetch_seeds)
         idx = self.seeds.upload(idx)
+        if self._use_graph_step():
+            if self._graphed is None:
+                self._graphed = GraphedStep(self.model, self.flat, self.optimizer)
+            return self._graphed(X.contiguous(), idx, h_lambda, h_c, a_lambda)
         eps = None
         if self.world > 1:
             # every rank holds the same generator state: draw the global noise and keep this rank's episodes
             eps = cdist.draw_eps(a.batch_size, a.sample_size, a.train_mc_sample_size, a.latent_size, self.device,
                                  self.rank, self.world)
-        if self._use_graph_step():
-            if self._graphed is None:
-                self._graphed = GraphedStep(self.model, self.flat, self.optimizer)
-            return self._graphed(X.contiguous(), idx, h_lambda, h_c, a_lambda)
         X_rec, rec_loss, kl_loss, h_augment, h = self.model(X, h_lambda, h_c, a_lambda, eps=eps, init_idx=idx)
         (rec_loss + kl_loss + h_augment).backward()
         self.flat.allreduce()
@@ -121,10 +122,12 @@ class Trainer(object):
         return rec_loss, kl_loss, h_augment, h
 
     def _use_graph_step(self):
-        """--graph-step auto: the feature variants in a single process (their step is bound by the host's launch rate;
-        the Omniglot step is bound by its kernels: cmvae_amd/graph_step.py); on / off force it."""
+        """--graph-step auto: the feature variants (their step is bound by the host's launch rate; the Omniglot step is
+        bound by its kernels and exchanges BatchNorm statistics inside the step: cmvae_amd/graph_step.py); on / off
+        force it (on: single process only for Omniglot)."""
         mode = getattr(self.args, 'graph_step', 'auto')
-        if mode == 'off' or self.world > 1 or getattr(self.args, 'debug', False) or ops.CHECK_INDICES:
+        if mode == 'off' or (self.world > 1 and self.variant == 'omniglot') or getattr(self.args, 'debug', False) \
+                or ops.CHECK_INDICES:
             return False
         return mode == 'on' or self.variant != 'omniglot'
 
@@ -185,6 +188,7 @@ class Trainer(object):
         self.flat = cdist.FlatGrads(self.model.parameters()).overlap_tail(self.model.tail_param_count())
         self.optimizer = FlatAdam(self.flat, lr=self.args.lr, weight_decay=self.args.weight_decay)
         self._graphed = None                     # graphs of the previous model's buffers are void
+        self._pipe = None
         if resume_optimizer and 'optimizer' in state:
             self.optimizer.load_state_dict(state['optimizer'])
         return state
@@ -218,10 +222,19 @@ class Trainer(object):
         if eb % self.world:
             raise ValueError('eval batch size %d is not divisible by %d ranks' % (eb, self.world))
         sl = cdist.shard_slice(eb, self.rank, self.world)
-        # the calls are independent: their kernel chains overlap on a few HIP streams (cmvae_amd/pipeline.py)
-        pipe = PredictionPipeline(self.model, getattr(a, 'eval_streams', None) or 8)
+        # the calls are independent: their kernel chains overlap on a few HIP streams (cmvae_amd/pipeline.py).  The
+        # pipeline is kept across evaluations — its graphs read weights and running statistics at replay time — and a
+        # handful of calls (debug runs) is not worth the streams' captures: those go through the plain loop.
+        n_calls = max(1, -(-a.eval_episodes // eb))
+        n_streams = getattr(a, 'eval_streams', None) or 8
+        if n_calls < 3 * n_streams:
+            pipe = PredictionPipeline(self.model, 1)
+        else:
+            if self._pipe is None or self._pipe.model is not self.model or self._pipe.n != n_streams:
+                self._pipe = PredictionPipeline(self.model, n_streams)
+            pipe = self._pipe
         targets = []
-        for _ in range(max(1, -(-a.eval_episodes // eb))):
+        for _ in range(n_calls):
             X_tr, y_tr, X_te, y_te = self.data.generate_test_episode(way=a.way, shot=shot, query=a.query,
                                                                      n_episodes=eb, test=test)
             pipe.submit(X_tr[sl].contiguous(), y_tr[sl].contiguous(), X_te[sl].contiguous())

@@ -118,3 +118,86 @@ def test_two_ranks_on_hip_kernels_equal_one_process(device, shape):
     assert torch.equal(out[0]['grads'], out[1]['grads'])
     assert torch.equal(out[0]['w'], out[1]['w'])                            # the ranks stay in lock step
     assert torch.equal(out[0]['bn'], out[1]['bn'])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the feature models' step replayed from a HIP graph with several ranks (cmvae_amd/graph_step.py): graph up to the
+# gradient pack, exchange and Adam after the replay
+FB, FS, FM, FK, FD, FSTEPS = 4, 5, 16, 5, 256, 6
+
+
+def _feat_model(device):
+    from cmvae_amd.model import FeatureGMVAE
+    torch.manual_seed(8)
+    return FeatureGMVAE(input_shape=FD, component_size=FK, train_mc_sample_size=FM, test_mc_sample_size=FM,
+                        unsupervised_em_iters=3, semisupervised_em_iters=3).to(device)
+
+
+def _feat_batches():
+    g = torch.Generator().manual_seed(12)
+    return [torch.relu(torch.randn(FB, FS, FD, generator=g)) for _ in range(FSTEPS)]
+
+
+def _graph_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    from cmvae_amd import dist as cdist
+    from cmvae_amd.graph_step import GraphedStep
+    from cmvae_amd.linear import FlatAdam
+    cdist.init_from_env('gloo')
+    device = torch.device('cuda:0')
+    model = _feat_model(device)
+    flat = cdist.FlatGrads(model.parameters()).overlap_tail(model.tail_param_count())
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
+    stepper = GraphedStep(model, flat, opt)
+    sl = cdist.shard_slice(FB)
+    np.random.seed(31)
+    torch.manual_seed(32)
+    losses = []
+    for X in _feat_batches():
+        idx = torch.from_numpy(cdist.draw_em_init(FS * FM, FK, FB)).to(device)
+        losses.append([float(t) for t in stepper(X[sl].to(device).contiguous(), idx, 0.1, 0.1, 1e-3)])
+    assert len(stepper.graphs) == 1 and stepper.calls == FSTEPS
+    out[rank] = dict(losses=torch.tensor(losses), w=model.proj[0].weight.detach().cpu().clone())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_graphed_feature_step_equals_one_process(device):
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_graph_worker, args=(world, port, out), nprocs=world, join=True)
+    from cmvae_amd import dist as cdist
+    from cmvae_amd.linear import FlatAdam
+    model = _feat_model(device)
+    w0 = model.proj[0].weight.detach().cpu().clone()
+    flat = cdist.FlatGrads(model.parameters())
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
+    np.random.seed(31)
+    torch.manual_seed(32)
+    losses = []
+    for X in _feat_batches():
+        idx = torch.from_numpy(cdist._draw_em_init_numpy(FS * FM, FK, FB)).to(device)
+        model.train()
+        flat.zero()
+        _, rec, kl, ha, h = model(X.to(device), 0.1, 0.1, 1e-3, init_idx=idx)
+        (rec + kl + ha).backward()
+        flat.allreduce()
+        opt.step()
+        losses.append([float(t.detach()) for t in (rec, kl, ha, h)])
+    losses = torch.tensor(losses)
+    mean_losses = (out[0]['losses'] + out[1]['losses']) / 2        # means over equal shards; h terms replicated
+    print('  graphed 2-rank vs eager 1-process losses, max rel %.2e'
+          % float(((mean_losses - losses).abs() / losses.abs().clamp_min(1e-6)).max()))
+    assert torch.allclose(mean_losses, losses, rtol=1e-4, atol=1e-6), (mean_losses, losses)
+    assert torch.equal(out[0]['w'], out[1]['w'])                    # the ranks stay in lock step
+    w = model.proj[0].weight.detach().cpu()
+    moved = (w - w0).abs() > 2e-3                                    # weights that took clear steps in one direction
+    assert float(moved.float().mean()) > 0.2
+    # Adam divides by sqrt(v): an element whose gradient is rounding noise in some step may differ by a fraction of
+    # that step's lr; nearly all elements agree far below it, none differs by a whole step
+    d = (out[0]['w'] - w)[moved].abs()
+    print('  weights after %d steps: median |d| %.1e, 99th percentile %.1e, max %.1e'
+          % (FSTEPS, float(d.median()), float(d.quantile(0.99)), float(d.max())))
+    assert float(d.quantile(0.99)) < 1e-4 and float(d.max()) < 1e-3

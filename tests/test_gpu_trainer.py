@@ -175,6 +175,21 @@ def test_graphed_step_equals_eager_step(device):
     for p1, p2 in zip(m1.parameters(), m2.parameters()):
         assert float((p1 - p2).detach().abs().max()) <= 2e-5 * float(p1.detach().abs().max()) + 1e-7
     assert o2.state_dict()['step'] == 8 and o1.state_dict()['step'] == 8
-    # other loss constants: a second graph, no new warm-up
-    stepper(batches[0], seeds[0], 0.2, 0.1, 1e-3)
-    assert len(stepper.graphs) == 2
+    # other loss constants (--dual-ascent moves them once per epoch): the graph of that shape is replaced, not kept
+    # — one graph and one pool of activations per shape however often the constants change — and the new values act
+    from cmvae_amd.trainer import dual_ascent_update
+    h_lambda, h_c, h_old = 0.1, 0.1, float('inf')
+    for _ in range(3):
+        out = stepper(batches[0], seeds[0], h_lambda, h_c, 1e-3)
+        rec_, kl_, ha_, h_ = (float(t) for t in out)
+        A = m2.causal.get_w().detach()
+        assert len(stepper.graphs) == 1
+        h_lambda, h_c, h_old = dual_ascent_update(h_, h_lambda, h_c, h_old)
+    assert h_lambda > 0.1                                    # the schedule did move the constants
+    # the last replay used the constants it was called with (A read after the step: one Adam update of lr 1e-3 away)
+    out = stepper(batches[0], seeds[0], h_lambda, h_c, 1e-3)
+    A = m2.causal.get_w().detach()
+    h_now = float(out[3])
+    assert abs(float(out[2]) - (h_lambda * h_now + 0.5 * h_c * h_now ** 2 + 1e-3 * float(A.abs().sum()))) \
+        <= 2e-2 * abs(float(out[2]))
+    assert len(stepper.graphs) == 1
