@@ -26,6 +26,10 @@
 #endif
 
 namespace cmvae {
+#if CMVAE_ABLATE == 30      // profiling build: every weight-stationary workgroup logs (start, end) on the 100 MHz wall clock + tiles
+__device__ unsigned long long g_wg_times[3 * 4096];
+__device__ unsigned long long g_wg_quarters[4 * 4096];     // wall clock when the workgroup had done 1/4, 1/2, 3/4, 7/8 of its tiles
+#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -230,6 +234,48 @@ __device__ __forceinline__ float4 transform_a(float4 v, bool ok, const float4& s
     v.w = ok ? v.w : 0.f;
     return v;
 }
+
+// The same fold in ONE instruction per channel pair: v_pk_fma_f32 with the CLAMP modifier clamps its result to [0, 1],
+// which is a ReLU as long as nothing reaches 1 — so the fold constants are scaled by 2^-60 (scale * 2^-60, shift * 2^-60:
+// the folded activation comes out as relu(bn(y)) * 2^-60, exactly, powers of two commute with the rounding of the fma)
+// and the other MFMA operand carries the 2^60 (weights staged into LDS as W * 2^60; the streaming weight gradient
+// multiplies its accumulators by 2^60 once, at the end).  Products and sums are bit for bit those of the unscaled
+// operands (tools/bin/clamp_test; an activation below 2^-66 would be flushed, far below fp32 resolution of any sum it
+// enters).  16 VALU instructions per 32 operand values instead of 16 + 32 v_max: every VALU instruction next to the
+// MFMAs costs ~5 cycles of the SIMD's MFMA time (tools/mfma_valu_cost.hip).
+constexpr float FOLD_UP = 0x1p60f, FOLD_DOWN = 0x1p-60f;
+__device__ __forceinline__ floatx2 pk_fma_clamp01(floatx2 a, floatx2 b, floatx2 c) {
+    floatx2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// sc, sh: the fold constants times FOLD_DOWN; returns relu(v * scale + shift) * FOLD_DOWN (v itself without a fold)
+template <bool HAS_T>
+__device__ __forceinline__ float4 fold_a_scaled(float4 v, const float4& sc, const float4& sh) {
+    if (HAS_T) {
+        const floatx2 lo = pk_fma_clamp01(floatx2{v.x, v.y}, floatx2{sc.x, sc.y}, floatx2{sh.x, sh.y});
+        const floatx2 hi = pk_fma_clamp01(floatx2{v.z, v.w}, floatx2{sc.z, sc.w}, floatx2{sh.z, sh.w});
+        v = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    return v;
+}
+// The same for a consumer that may follow at once: a v_mfma must not read a VGPR within two wait states of the VALU
+// instruction that wrote it, and the compiler's hazard recognizer does not look into inline asm (it left one wait
+// state; the first MFMA behind the fold then read the register's previous value: tools/bin/hazard_test gives 2 as the
+// distance that works).  Both halves and the wait states are one asm block, correct wherever it is scheduled.
+template <bool HAS_T>
+__device__ __forceinline__ float4 fold_a_scaled_guarded(float4 v, const float4& sc, const float4& sh) {
+    if (HAS_T) {
+        floatx2 lo, hi;
+        asm("v_pk_fma_f32 %0, %2, %3, %4 clamp\n\tv_pk_fma_f32 %1, %5, %6, %7 clamp\n\ts_nop 1"
+            : "=&v"(lo), "=v"(hi)
+            : "v"(floatx2{v.x, v.y}), "v"(floatx2{sc.x, sc.y}), "v"(floatx2{sh.x, sh.y}), "v"(floatx2{v.z, v.w}),
+              "v"(floatx2{sc.z, sc.w}), "v"(floatx2{sh.z, sh.w}));
+        v = make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+    return v;
+}
+__device__ __forceinline__ float4 scaled4(const float4& v, float f) { return make_float4(v.x * f, v.y * f, v.z * f, v.w * f); }
 
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {
@@ -638,6 +684,10 @@ __device__ __forceinline__ void wstat_body(
     float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps, int bid, int nblk, int nb_in, int stats_bid,
     int stats_nblk, const BnBwd& bnb = BnBwd{}) {
     constexpr int BMT = 32 * NW;                                   // rows per tile: 32 per wave
+#if CMVAE_ABLATE == 30
+    if (threadIdx.x == 0 && stats_bid < 4096) g_wg_times[3 * stats_bid] = wall_clock64();
+    int tiles_done = 0;
+#endif
     extern __shared__ __align__(16) float wstat_smem[];
     float* Ws = wstat_smem;                                        // [ntaps][64][LDA]
     int* opix = reinterpret_cast<int*>(Ws + ntaps * 64 * LDA);     // [2][NW waves][32 rows]
@@ -651,15 +701,16 @@ __device__ __forceinline__ void wstat_body(
         for (int t = 0; t < ntaps; ++t)
             for (int row = rb; row < 64; row += 4 * NW)
                 *reinterpret_cast<float4*>(&Ws[(t * 64 + row) * LDA + 4 * q]) =
-                    *reinterpret_cast<const float4*>(Wn + g.w_off[tap0 + t] + (long)row * g.w_pitch);
+                    scaled4(*reinterpret_cast<const float4*>(Wn + g.w_off[tap0 + t] + (long)row * g.w_pitch),
+                            HAS_T ? FOLD_UP : 1.f);          // the folded operand arrives times 2^-60 (fold_a_scaled)
     }
     // BatchNorm fold of this lane's channels (8kk + 4h .. +3)
     float4 sc[HAS_T ? 8 : 1], sh[HAS_T ? 8 : 1];
     if (HAS_T) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            sc[kk] = *reinterpret_cast<const float4*>(a_scale + 8 * kk + 4 * h);
-            sh[kk] = *reinterpret_cast<const float4*>(a_shift + 8 * kk + 4 * h);
+            sc[kk] = scaled4(*reinterpret_cast<const float4*>(a_scale + 8 * kk + 4 * h), FOLD_DOWN);
+            sh[kk] = scaled4(*reinterpret_cast<const float4*>(a_shift + 8 * kk + 4 * h), FOLD_DOWN);
         }
     }
     const int ntiles = (g.rows_total + BMT - 1) / BMT;
@@ -735,6 +786,9 @@ __device__ __forceinline__ void wstat_body(
         const int grp = vv / npos;
         return (vv - grp * npos) * gimg + grp;
     };
+#if CMVAE_ABLATE == 30
+    const int my_tiles = v < v_end ? (v_end - v + v_step - 1) / v_step : 0;      // this workgroup's share of the tiles
+#endif
     int tile = tile_of(v);
     TileInfo ti = taps.tile<PM>(g, lane, tile * BMT, BMT, tap0, ntaps);
     unsigned mask = ti.mask;
@@ -746,12 +800,14 @@ __device__ __forceinline__ void wstat_body(
         float4 a[8];
         {
             const bool ok = ok_next;
-            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) {        // uniform: every row of the wave is inside the image
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) a[kk] = fold_a<HAS_T>(ra[kk], sc[HAS_T ? kk : 0], sh[HAS_T ? kk : 0]);
-            } else {
+            for (int kk = 0; kk < 8; ++kk) a[kk] = fold_a_scaled<HAS_T>(ra[kk], sc[HAS_T ? kk : 0], sh[HAS_T ? kk : 0]);
+            if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) {        // uniform; rare: some row of the wave is outside the image
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) a[kk] = transform_a<HAS_T>(ra[kk], ok, sc[HAS_T ? kk : 0], sh[HAS_T ? kk : 0]);
+                for (int kk = 0; kk < 8; ++kk) {
+                    a[kk].x = ok ? a[kk].x : 0.f; a[kk].y = ok ? a[kk].y : 0.f;
+                    a[kk].z = ok ? a[kk].z : 0.f; a[kk].w = ok ? a[kk].w : 0.f;
+                }
             }
         }
         const unsigned rest = taps_above(mask, t);
@@ -841,6 +897,15 @@ __device__ __forceinline__ void wstat_body(
             acc0 = floatx16{};
             acc1 = floatx16{};
             par ^= 1;
+#if CMVAE_ABLATE == 30
+            ++tiles_done;
+            if (threadIdx.x == 0 && stats_bid < 4096) {
+                if (tiles_done == my_tiles / 4) g_wg_quarters[4 * stats_bid] = wall_clock64();
+                if (tiles_done == my_tiles / 2) g_wg_quarters[4 * stats_bid + 1] = wall_clock64();
+                if (tiles_done == 3 * my_tiles / 4) g_wg_quarters[4 * stats_bid + 2] = wall_clock64();
+                if (tiles_done == 7 * my_tiles / 8) g_wg_quarters[4 * stats_bid + 3] = wall_clock64();
+            }
+#endif
             tile = ntile;
             mask = nmask;
         } else if (last) {
@@ -874,11 +939,26 @@ __device__ __forceinline__ void wstat_body(
             acc0 = floatx16{};
             acc1 = floatx16{};
             par ^= 1;
+#if CMVAE_ABLATE == 30
+            ++tiles_done;
+            if (threadIdx.x == 0 && stats_bid < 4096) {
+                if (tiles_done == my_tiles / 4) g_wg_quarters[4 * stats_bid] = wall_clock64();
+                if (tiles_done == my_tiles / 2) g_wg_quarters[4 * stats_bid + 1] = wall_clock64();
+                if (tiles_done == 3 * my_tiles / 4) g_wg_quarters[4 * stats_bid + 2] = wall_clock64();
+                if (tiles_done == 7 * my_tiles / 8) g_wg_quarters[4 * stats_bid + 3] = wall_clock64();
+            }
+#endif
             tile = ntile;
             mask = nmask;
         }
         t = tn;
     }
+#if CMVAE_ABLATE == 30
+    if (threadIdx.x == 0 && stats_bid < 4096) {
+        g_wg_times[3 * stats_bid + 1] = wall_clock64();
+        g_wg_times[3 * stats_bid + 2] = tiles_done;
+    }
+#endif
     if (stats_part) {
         ssum0 += sum0p.x + sum0p.y; ssum1 += sum1p.x + sum1p.y;
         ssq0 += sq0p.x + sq0p.y; ssq1 += sq1p.x + sq1p.y;
@@ -1169,8 +1249,10 @@ __device__ __forceinline__ void wgrad_stream_body(const ConvGeom& g, int tap0, i
     for (int u = 0; u < 2; ++u) {
         sc[u] = make_float4(1.f, 1.f, 1.f, 1.f); sh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (HAS_T && t_u[u] < nt) {
-            sc[u] = *reinterpret_cast<const float4*>(a_scale + g.a_col[tap0 + t_u[u]] + 4 * i);
-            sh[u] = *reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t_u[u]] + 4 * i);
+            // times 2^-60: the fold is one clamped v_pk_fma_f32 per channel pair (fold_a_scaled); the accumulators
+            // get the 2^60 back when they are written out
+            sc[u] = scaled4(*reinterpret_cast<const float4*>(a_scale + g.a_col[tap0 + t_u[u]] + 4 * i), FOLD_DOWN);
+            sh[u] = scaled4(*reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t_u[u]] + 4 * i), FOLD_DOWN);
         }
     }
     // lane (i, kq): channels 4i .. 4i+3 of image kq of a 4-row group; everything else of an address is uniform, so the
@@ -1237,7 +1319,7 @@ __device__ __forceinline__ void wgrad_stream_body(const ConvGeom& g, int tap0, i
 #if CMVAE_ABLATE != 8
             if (!((valid >> u) & 1u)) continue;                  // uniform
 #endif
-            const float4 a = transform_a<HAS_T>(ra[slot][u], true, sc[u], sh[u]);
+            const float4 a = fold_a_scaled_guarded<HAS_T>(ra[slot][u], sc[u], sh[u]);
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int ja = 0; ja < 4; ++ja)
@@ -1280,6 +1362,12 @@ __device__ __forceinline__ void wgrad_stream_body(const ConvGeom& g, int tap0, i
         g_clock_probe[0] = clock64() - clk0; g_clock_probe[1] = wall_clock64() - wall0;
     }
 #endif
+    if (HAS_T) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[u][k] *= FOLD_UP;          // exact: the operand was folded times 2^-60
+    }
     // add the row streams of a tap pair (wave p == 0 keeps the sum): lane-major LDS image of the 128 accumulators
     float* cb = comb + tp * 8192 + lane;
     for (int k = 1; k < P; ++k) {
@@ -2093,6 +2181,14 @@ extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, con
     return 0;
 }
 
+#if CMVAE_ABLATE == 30
+extern "C" int cmvae_debug_wg_times(unsigned long long* out_host, int n_wg) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(cmvae::g_wg_times), (size_t)n_wg * 24) == hipSuccess ? 0 : -1;
+}
+extern "C" int cmvae_debug_wg_quarters(unsigned long long* out_host, int n_wg) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(cmvae::g_wg_quarters), (size_t)n_wg * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 #if CMVAE_ABLATE == 20
 extern "C" int cmvae_debug_clock_probe(long long* out2) {
     return hipMemcpyFromSymbol(out2, HIP_SYMBOL(cmvae::g_clock_probe), 16) == hipSuccess ? 0 : -1;

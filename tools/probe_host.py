@@ -4,19 +4,21 @@ import numpy as np, torch
 sys.path.insert(0, '.')
 import bench
 from cmvae_amd import dist as cdist
+import os
+cfg = bench.CONFIGS[os.environ.get('CMVAE_PROBE_CONFIG', 'o20')]
 dev = torch.device('cuda:0')
-model = bench.build_model(dev)
+model = bench.build_model(dev, cfg)
 flat = cdist.FlatGrads(model.parameters())
 from cmvae_amd.linear import FlatAdam
-opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
+opt = FlatAdam(flat, lr=cfg['lr'], weight_decay=5e-5)
 np.random.seed(1); torch.manual_seed(1)
-X = bench.synth_images(bench.B_PER_GPU, bench.SAMPLE, 'cpu', 100).to(dev)
-N = bench.SAMPLE * bench.MC
+X = bench.synth_batch(cfg, cfg['batch'], cfg['sample'], 'cpu', 100).to(dev)
+N = cfg['sample'] * cfg['mc']
 
 def step():
     model.train(); flat.zero()
-    idx = torch.from_numpy(cdist.draw_em_init(N, bench.WAY, bench.B_PER_GPU, 0, 1)).pin_memory().to(dev, non_blocking=True)
-    _, rec, kl, h, _ = model(X, 0.1, 0.1, 1e-4, init_idx=idx)
+    idx = torch.from_numpy(cdist.draw_em_init(N, cfg['way'], cfg['batch'], 0, 1)).pin_memory().to(dev, non_blocking=True)
+    _, rec, kl, h, _ = model(X, *cfg['consts'], init_idx=idx)
     (rec + kl + h).backward()
     flat.allreduce(); opt.step()
 
