@@ -103,11 +103,8 @@ SIGNATURES = {
     'cmvae_enc_conv1_pool_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                          c_void_p]),
     'cmvae_enc_conv1_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    'cmvae_enc_conv1_wgrad': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'cmvae_enc_conv1_wgrad_bn': (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_enc_conv1_bwd_lin_cols': (c_int, []),
     'cmvae_enc_conv1_tap_sums': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'cmvae_enc_conv1_bwd_lin': (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_enc_conv1_bwd_lin_rc_grid': (c_int, [c_int]),
     'cmvae_enc_conv1_bwd_lin_rc': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_void_p, c_void_p]),
     'cmvae_enc_conv1_lin_finalize': (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int] + [c_void_p] * 11),

@@ -1590,8 +1590,7 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
     // pixel-major only pays (and only keeps its tiles at one grid position) from a tile's worth of images on
     const int npix = c->Hg * c->Wg;
     g.pm_nimg = (c->pixel_major && npix > 0 && c->rows_total / npix >= 64) ? c->rows_total / npix : 0;
-    static const bool xcd_order = [] { const char* e = getenv("CMVAE_XCD_ORDER"); return !(e && e[0] == '0'); }();
-    g.xcd_order = xcd_order ? 1 : 0;
+    g.xcd_order = 1;
     for (int t = 0; t < 32; ++t) { g.dy[t] = c->dy[t]; g.dx[t] = c->dx[t]; g.a_col[t] = c->a_col[t]; g.w_off[t] = c->w_off[t]; }
     return g;
 }
@@ -1753,15 +1752,9 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     return check_launch("conv_gemm_kernel");
 }
 
-// CMVAE_SPLIT_DGRAD=0 keeps the 16-tap data gradients on the direct kernel (A/B measurements)
-static int split_dgrad_min_rows() {
-    static const int v = [] {
-        const char* e = getenv("CMVAE_SPLIT_DGRAD");
-        const int r = e ? atoi(e) : 1;
-        return r == 0 ? 0x7fffffff : (r == 1 ? 3 * 256 * 256 : r);      // 0: off, 1: default, else: the threshold
-    }();
-    return v;
-}
+// rows from which a 16-tap data gradient runs as two accumulating weight-stationary launches (below it the direct
+// kernel is faster: layer 1's 153 600 rows take 133 us there against 79 + 84 us split)
+static int split_dgrad_min_rows() { return 3 * 256 * 256; }
 // every grid position keeps at least one in-image tap in taps [0, n/2) and in [n/2, n)
 static bool halves_nonempty(const ConvGeom& g) {
     const int h0 = g.ntaps / 2;
@@ -1819,12 +1812,6 @@ extern "C" size_t cmvae_conv_wgrad_workspace_bytes(int rows_total) {
     return align_up((size_t)nblk * 4 * 4096 * sizeof(float)) + align_up((size_t)nblk * 64 * sizeof(float));
 }
 
-// CMVAE_WGRAD_STREAM=0 keeps every launch on the LDS-staged kernel (A/B measurements)
-static bool wgrad_stream_enabled() {
-    static const bool on = [] { const char* e = getenv("CMVAE_WGRAD_STREAM"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 // ny 64-column blocks of G (dW advances by y_stride per block) x the taps of g, in as few launches as possible
 static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale, const float* a_shift,
                         const float* G, int g_pitch, int g_col, const int64_t* tap_off_host, int64_t s_ci,
@@ -1843,7 +1830,7 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
     {   // 5 .. 16 taps of one gradient column block (the 3x3 convs: 4 + 4 + 1): the tap groups side by side in one
         // launch and one reduction, workgroups in proportion to each group's tap work
         const int npix = g.Hg * g.Wg, nimg = g.rows_total / npix;
-        if (wgrad_stream_enabled() && ny == 1 && g_col == 0 && g.ntaps > 4 && g.ntaps <= 16 && g.ntaps % 4 != 0 &&
+        if (ny == 1 && g_col == 0 && g.ntaps > 4 && g.ntaps <= 16 && g.ntaps % 4 != 0 &&
             g.rows_total % npix == 0 && nimg % 16 == 0 && (long)nimg * g.Ho * g.Wo * g_pitch < (1L << 31)) {
             ConvGeomMulti p{};
             WgradMultiOut mo{};
@@ -1892,7 +1879,7 @@ static int wgrad_launch(const ConvGeom& g, const float* A, const float* a_scale,
         const bool pm = g.pm_nimg > 0;
         const int npix = g.Hg * g.Wg, nimg = g.rows_total / npix;
         // (the streaming kernel addresses the gradient with 32-bit element offsets, like the operand)
-        if (wgrad_stream_enabled() && g.rows_total % npix == 0 && nimg % 16 == 0 &&
+        if (g.rows_total % npix == 0 && nimg % 16 == 0 &&
             (long)nimg * g.Ho * g.Wo * g_pitch < (1L << 31)) {
             if (a_scale) hipLaunchKernelGGL(conv_wgrad_stream_kernel<true>, grid, dim3(256), 0, st, g, t0, nt, nimg, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp);
             else hipLaunchKernelGGL(conv_wgrad_stream_kernel<false>, grid, dim3(256), 0, st, g, t0, nt, nimg, A, a_scale, a_shift, G, g_pitch, g_col, part, dbp);
@@ -1949,7 +1936,7 @@ extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, c
     CMVAE_REQUIRE(workspace_bytes >= cmvae_conv_wgrad_workspace_bytes(0), "cmvae_conv_wgrad_multi: workspace too small");
     ConvGeomMulti p{};
     hipStream_t st = (hipStream_t)stream;
-    bool streamable = wgrad_stream_enabled();
+    bool streamable = true;
     int nimg = -1;
     for (int k = 0; k < ngeom; ++k) {
         p.g[k] = to_geom(&geoms[k]);
@@ -2024,12 +2011,6 @@ static ConvGeom linear_geom(int rows, int K, int N, int a_pitch, int o_pitch) {
     return g;
 }
 
-// CMVAE_LINEAR_WSTAT=0 keeps every nn.Linear launch on the direct kernel (A/B measurements)
-static bool linear_wstat_enabled() {
-    static const bool on = [] { const char* e = getenv("CMVAE_LINEAR_WSTAT"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const float* bias, int act, int ncb,
                        float* out, hipStream_t st, const float* mse_target = nullptr, int mse_M = 1, int mse_pitch = 0,
                        float* mse_part = nullptr) {
@@ -2037,7 +2018,7 @@ static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const
     // direct kernel would be one 64-deep tap between two barriers; here a workgroup keeps its column block's weight
     // tile in LDS and walks the row tiles without a barrier (147 vs 176 us on [38400, 64]).  Measured slower or equal
     // for in_features = 256 (68 vs 66 us) and for the small launches (17-19 vs 15 us), which stay on the direct kernel.
-    if (!mse_target && g.ntaps == 1 && ncb >= 8 && g.rows_total >= 8192 && linear_wstat_enabled()) {
+    if (!mse_target && g.ntaps == 1 && ncb >= 8 && g.rows_total >= 8192) {
         const float* none = nullptr;
         switch (act) {
             case 0: return launch_wstat<0, false, 4, false>(g, A, Wt, bias, none, none, out, nullptr, 0, ncb, 0, g.ntaps, st);

@@ -133,117 +133,6 @@ __global__ __launch_bounds__(256) void enc_conv1_pool_kernel(const float* __rest
     }
 }
 
-// part[blk][640] = { dW[64][9], db[64] },  dW[c][t] = sum_r dy[r][c] * x[src(r,t)]
-__global__ __launch_bounds__(256) void enc_conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              int H, int W, long rows, float* __restrict__ part) {
-    __shared__ float red[16 * 640];
-    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
-    float acc[4][9], db[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
-    const int hw = H * W;
-    for (long r = (long)blockIdx.x * 16 + rb; r < rows; r += (long)gridDim.x * 16) {
-        const long n = r / hw;
-        const int rem = (int)(r - n * hw);
-        const int py = rem / W, px = rem - py * W;
-        const float* xi = x + n * hw;
-        const float4 g4 = reinterpret_cast<const float4*>(dy + r * EC)[q];
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) db[c] += g[c];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int sy = py + ky - 1;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int sx = px + kx - 1;
-                const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
-                const float xv = ok ? xi[sy * W + sx] : 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c][ky * 3 + kx] = fmaf(g[c], xv, acc[c][ky * 3 + kx]);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) red[rb * 640 + (4 * q + c) * 9 + t] = acc[c][t];
-        red[rb * 640 + 576 + 4 * q + c] = db[c];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 640; e += 256) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += red[r * 640 + e];
-        part[(long)blockIdx.x * 640 + e] = s;
-    }
-}
-
-// The same with the BatchNorm-backward apply on the load: dy = scale * (dybn - c1 - xhat * c2), xhat = (y - mean) *
-// invstd.  The first layer's gradient has no other consumer (there is no data gradient below conv1), so the apply
-// pass — read dybn and y, write dy — and this kernel's read of dy become one read of dybn and y.
-__global__ __launch_bounds__(256) void enc_conv1_wgrad_bn_kernel(const float* __restrict__ x,
-                                                                 const float* __restrict__ dybn,
-                                                                 const float* __restrict__ y,
-                                                                 const float* __restrict__ scale,
-                                                                 const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd,
-                                                                 const float* __restrict__ c1,
-                                                                 const float* __restrict__ c2, int H, int W, long rows,
-                                                                 float* __restrict__ part) {
-    __shared__ float red[16 * 640];
-    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4;
-    const float4 sc = reinterpret_cast<const float4*>(scale)[q], mu = reinterpret_cast<const float4*>(mean)[q];
-    const float4 is = reinterpret_cast<const float4*>(invstd)[q];
-    const float4 a1 = reinterpret_cast<const float4*>(c1)[q], a2 = reinterpret_cast<const float4*>(c2)[q];
-    float acc[4][9], db[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
-    const int hw = H * W;
-    for (long r = (long)blockIdx.x * 16 + rb; r < rows; r += (long)gridDim.x * 16) {
-        const long n = r / hw;
-        const int rem = (int)(r - n * hw);
-        const int py = rem / W, px = rem - py * W;
-        const float* xi = x + n * hw;
-        const float4 g4 = reinterpret_cast<const float4*>(dybn + r * EC)[q];
-        const float4 v = reinterpret_cast<const float4*>(y + r * EC)[q];
-        // the arithmetic of bn_relu_bwd_apply_kernel (masked = 1), element for element
-        const float g[4] = {sc.x * (g4.x - a1.x - (v.x - mu.x) * is.x * a2.x), sc.y * (g4.y - a1.y - (v.y - mu.y) * is.y * a2.y),
-                            sc.z * (g4.z - a1.z - (v.z - mu.z) * is.z * a2.z), sc.w * (g4.w - a1.w - (v.w - mu.w) * is.w * a2.w)};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) db[c] += g[c];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int sy = py + ky - 1;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int sx = px + kx - 1;
-                const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
-                const float xv = ok ? xi[sy * W + sx] : 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c][ky * 3 + kx] = fmaf(g[c], xv, acc[c][ky * 3 + kx]);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) red[rb * 640 + (4 * q + c) * 9 + t] = acc[c][t];
-        red[rb * 640 + 576 + 4 * q + c] = db[c];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 640; e += 256) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += red[r * 640 + e];
-        part[(long)blockIdx.x * 640 + e] = s;
-    }
-}
-
 // ------------------------------------------------------------------ relu(bn(y)) -> maxpool 2x2 (ceil)
 __device__ __forceinline__ float4 fold4(const float4 v, const float4 sc, const float4 sh) {
     return make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f),
@@ -447,114 +336,7 @@ __device__ __forceinline__ void tap_stats_block(const float* __restrict__ part_m
 }
 
 constexpr int LIN1_COLS = 2 * EC + 9 * EC;           // s1, s2 [64] each, P1 [64][9]
-__global__ __launch_bounds__(256) void enc_conv1_bwd_lin_kernel(
-    const float* __restrict__ d_pool, const float* __restrict__ y, const float* __restrict__ x,
-    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ part_m, float npix_loc, int H, int W, int Ho, int Wo,
-    long orows, float* __restrict__ part) {
-    __shared__ float red[4 * LIN1_COLS];             // first the scratch of tap_stats_block (256 * 9 floats)
-    __shared__ float ms[9];
-    static_assert(4 * LIN1_COLS >= TAPM_BLOCKS * 9, "scratch");
-    const int q = threadIdx.x & 15, rb = threadIdx.x >> 4, lane = threadIdx.x & 63;
-    tap_stats_block<9>(part_m, red, ms);
-    float m[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) m[t] = ms[t] / npix_loc;      // the finalize kernel's expression, bit for bit
-    __syncthreads();                                 // red is reused for the final reduction
-    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
-    const float4 mu4 = reinterpret_cast<const float4*>(mean)[q], is4 = reinterpret_cast<const float4*>(invstd)[q];
-    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
-    float s1[4], s2[4], P1[4][9];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        s1[c] = s2[c] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) P1[c][t] = 0.f;
-    }
-    const int ohw = Ho * Wo;
-    const int pa = q >> 2, pb = q & 3;               // this thread's element of the window's 4x4 image patch
-    // (every thread runs the same number of iterations: the patch is exchanged with shuffles)
-    const long r_end = ((orows + 15) / 16) * 16;
-    for (long r = (long)blockIdx.x * 16 + rb; r < r_end; r += (long)gridDim.x * 16) {
-        const bool live = r < orows;
-        const long rr = live ? r : orows - 1;
-        const long n = rr / ohw;
-        const int rem = (int)(rr - n * ohw);
-        const int oy = rem / Wo, ox = rem - oy * Wo;
-        float4 g4 = reinterpret_cast<const float4*>(d_pool + rr * EC)[q];
-        if (!live) g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-        float raw[4][4], val[4][4];        // [window slot][channel]
-        bool in[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int sy = 2 * oy + (s >> 1), sx = 2 * ox + (s & 1);
-            in[s] = sy < H && sx < W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in[s]) v = reinterpret_cast<const float4*>(y + ((n * H + sy) * W + sx) * EC)[q];
-            const float4 f = fold4(v, sc, sh);
-            raw[s][0] = v.x; raw[s][1] = v.y; raw[s][2] = v.z; raw[s][3] = v.w;
-            val[s][0] = f.x; val[s][1] = f.y; val[s][2] = f.z; val[s][3] = f.w;
-        }
-        // the 4x4 patch of the image around the window (zero outside the image): one element per thread of the
-        // window's 16, handed round
-        float xp[4][4];
-        {
-            const int sy = 2 * oy - 1 + pa, sx = 2 * ox - 1 + pb;
-            const float mine = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(n * H + sy) * W + sx] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) xp[j >> 2][j & 3] = __shfl(mine, (lane & 48) | j);
-        }
-        float o[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int best = 0;
-            float bv = -INFINITY;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                if (in[s] && val[s][c] > bv) { bv = val[s][c]; best = s; }
-            const float gg = bv > 0.f ? g[c] : 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                o[s][c] = (s == best) ? gg : 0.f;
-                s2[c] = fmaf(o[s][c], (raw[s][c] - mu[c]) * is[c], s2[c]);
-            }
-            s1[c] += gg;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (!in[s]) continue;          // a pixel outside the image has no taps
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float xc = xp[(s >> 1) + ky][(s & 1) + kx] - m[ky * 3 + kx];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) P1[c][ky * 3 + kx] = fmaf(o[s][c], xc, P1[c][ky * 3 + kx]);
-                }
-        }
-    }
-    // the four window slots of a wave share q: two shuffles, then the four waves through LDS
-    const int w = threadIdx.x >> 6;
-    auto put = [&](int col, float v) {
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16) red[w * LIN1_COLS + col] = v;
-    };
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        put(4 * q + c, s1[c]);
-        put(EC + 4 * q + c, s2[c]);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) put(2 * EC + (4 * q + c) * 9 + t, P1[c][t]);
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < LIN1_COLS; e += 256)
-        part[(long)blockIdx.x * LIN1_COLS + e] =
-            (red[e] + red[LIN1_COLS + e]) + (red[2 * LIN1_COLS + e] + red[3 * LIN1_COLS + e]);
-}
-
-// The same pass with y recomputed from the image (conv1 is 9 multiply-adds per value; the arithmetic of
+// The pass, with y recomputed from the image (conv1 is 9 multiply-adds per value; the arithmetic of
 // enc_conv1_fwd_kernel / enc_conv1_pool_kernel, bit for bit, so the window maxima are the forward's): the 64-channel
 // pre-pooling activation of layer 1 is never stored.  One image per workgroup pass, zero-padded in LDS.
 __global__ __launch_bounds__(256) void enc_conv1_bwd_lin_rc_kernel(
@@ -747,27 +529,6 @@ extern "C" int cmvae_enc_conv1_pool_fwd(const float* x, const float* w, const fl
     return check_launch("enc_conv1_pool_kernel");
 }
 
-extern "C" int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, float* part, void* stream) {
-    cmvae::clear_stale_error();
-    CMVAE_REQUIRE(x && dy && part && n >= 1 && H >= 1 && W >= 1, "cmvae_enc_conv1_wgrad: bad arguments");
-    const long rows = (long)n * H * W;
-    hipLaunchKernelGGL(enc_conv1_wgrad_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, dy, H, W, rows,
-                       part);
-    return check_launch("enc_conv1_wgrad_kernel");
-}
-
-extern "C" int cmvae_enc_conv1_wgrad_bn(const float* x, const float* dybn, const float* y, const float* scale,
-                                       const float* mean, const float* invstd, const float* c1, const float* c2, int n,
-                                       int H, int W, float* part, void* stream) {
-    cmvae::clear_stale_error();
-    CMVAE_REQUIRE(x && dybn && y && scale && mean && invstd && c1 && c2 && part && n >= 1 && H >= 1 && W >= 1,
-                  "cmvae_enc_conv1_wgrad_bn: bad arguments");
-    const long rows = (long)n * H * W;
-    hipLaunchKernelGGL(enc_conv1_wgrad_bn_kernel, dim3(rp_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, dybn, y, scale,
-                       mean, invstd, c1, c2, H, W, rows, part);
-    return check_launch("enc_conv1_wgrad_bn_kernel");
-}
-
 extern "C" int cmvae_enc_conv1_bwd_lin_cols(void) { cmvae::clear_stale_error(); return LIN1_COLS; }
 
 extern "C" int cmvae_enc_conv1_tap_sums(const float* x, int n, int H, int W, float* part_m, void* stream) {
@@ -777,19 +538,6 @@ extern "C" int cmvae_enc_conv1_tap_sums(const float* x, int n, int H, int W, flo
     hipLaunchKernelGGL(enc_conv1_tap_sums_kernel, dim3(TAPM_BLOCKS), dim3(1024), 0, (hipStream_t)stream, x, H, W,
                        n * H * W, part_m);
     return check_launch("enc_conv1_tap_sums_kernel");
-}
-
-extern "C" int cmvae_enc_conv1_bwd_lin(const float* d_pool, const float* y, const float* x, const float* scale,
-                                      const float* shift, const float* mean, const float* invstd, const float* part_m,
-                                      int n, int H, int W, float* part, void* stream) {
-    cmvae::clear_stale_error();
-    CMVAE_REQUIRE(d_pool && y && x && scale && shift && mean && invstd && part_m && part && n >= 1 && H >= 1 && W >= 1,
-                  "cmvae_enc_conv1_bwd_lin: bad arguments");
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const long orows = (long)n * Ho * Wo;
-    hipLaunchKernelGGL(enc_conv1_bwd_lin_kernel, dim3(rp_grid(orows)), dim3(256), 0, (hipStream_t)stream, d_pool, y, x,
-                       scale, shift, mean, invstd, part_m, (float)((long)n * H * W), H, W, Ho, Wo, orows, part);
-    return check_launch("enc_conv1_bwd_lin_kernel");
 }
 
 extern "C" int cmvae_enc_conv1_bwd_lin_rc_grid(int n) { cmvae::clear_stale_error(); return n < 2048 ? (n < 1 ? 1 : n) : 2048; }

@@ -9,10 +9,6 @@ per layer: data-gradient GEMM with the BN-backward sums of the layer below from 
 apply of the layer below, weight gradient of all four phases in one launch.
 Pre-BatchNorm activations y1..y3 are the only tensors kept for the backward pass.
 """
-import ctypes
-
-import os
-
 import torch
 
 from . import conv
@@ -58,15 +54,11 @@ def bn_finalize(sums, count, bn, training_update=True):
     return scale, shift, mean, invstd
 
 
-# CMVAE_FUSED_BN_FINALIZE=0: column sums and finalize as two launches also in a single process (A/B measurements)
-FUSED_BN_FINALIZE = os.environ.get('CMVAE_FUSED_BN_FINALIZE', '1') not in ('', '0')
-
-
 def bn_stats_finalize(part, count, bn):
     """Training-mode fold (scale, shift, mean, invstd) from the conv GEMM's partial statistics [nblk,128]; count =
     values per channel over ALL ranks.  One process: one launch (sums, finalize, running statistics and the batch
     counter); several: column sums, all-reduce (collective C2), finalize."""
-    if _dist.world_size() > 1 or not FUSED_BN_FINALIZE or bn.momentum is None:
+    if _dist.world_size() > 1 or bn.momentum is None:
         return bn_finalize(_global_sums(colsum(part)), count, bn)
     dev = part.device
     scale, shift, mean, invstd = (torch.empty(64, device=dev) for _ in range(4))
@@ -81,7 +73,7 @@ def bn_stats_finalize(part, count, bn):
 def bn_bwd_sums_finalize(part, count):
     """(c1, c2, dgamma, dbeta) from partial BatchNorm-backward sums [nblk,128]; count = this rank's values per
     channel."""
-    if _dist.world_size() > 1 or not FUSED_BN_FINALIZE:
+    if _dist.world_size() > 1:
         return bn_bwd_finalize(colsum(part), count)
     dev = part.device
     c1, c2, dgamma, dbeta = (torch.empty(64, device=dev) for _ in range(4))
@@ -130,44 +122,10 @@ def convT_forward(x, n, Hi, k, weight, bias, fold_in, want_stats):
     wprep = weight.detach().permute(2, 3, 1, 0).contiguous()                 # [ky][kx][co][ci]: all k*k taps
     phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=PIXEL_MAJOR) for py in (0, 1) for px in (0, 1)]
     sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
-    if MULTI_PHASE:                      # all four phases in one launch
-        part = conv.conv_gemm_multi([g for g, _ in phases], x, wprep, y, bias=bias.detach(), a_scale=sc, a_shift=sh,
-                                    stats=want_stats)
-        return y, (part if want_stats else None)
-    part = None
-    if want_stats:
-        grids = [conv.gemm_grid(g.rows_total, 1) for g, _ in phases]
-        part = torch.empty(sum(grids), 128, device=x.device)
-    off = 0
-    sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
-    for i, (g, tap_idx) in enumerate(phases):
-        st = part[off:off + grids[i]] if want_stats else False
-        conv.conv_gemm(g, x, wprep, y, bias=bias.detach(), a_scale=sc, a_shift=sh, stats=st)
-        if want_stats:
-            off += grids[i]
+    # all four phases in one launch (conv_gemm_wstat_multi_kernel)
+    part = conv.conv_gemm_multi([g for g, _ in phases], x, wprep, y, bias=bias.detach(), a_scale=sc, a_shift=sh,
+                                stats=want_stats)
     return y, (part if want_stats else None)
-
-
-# CMVAE_CONV_MULTI=0: one launch per sub-pixel phase of a transposed conv instead of one per layer (A/B measurements)
-MULTI_PHASE = os.environ.get('CMVAE_CONV_MULTI', '1') not in ('', '0')
-
-# CMVAE_FUSED_BN_SUMS=0: the BatchNorm-backward sums in a pass of their own instead of the data gradient's epilogue
-FUSED_BN_SUMS = os.environ.get('CMVAE_FUSED_BN_SUMS', '1') not in ('', '0')
-
-# CMVAE_DEC_LINSUMS=0: the sums pass of the last layer's backward through the gradient tile (dec_out_bwd_kernel<0>)
-DEC_LINSUMS = os.environ.get('CMVAE_DEC_LINSUMS', '1') not in ('', '0')
-
-# CMVAE_BN_SIDE=1: the decoder's BatchNorm backward passes on a side stream next to the weight-gradient GEMMs (off by
-# default: measured slower inside the step, see _DecoderBCE.backward)
-BN_SIDE_STREAM = os.environ.get('CMVAE_BN_SIDE', '0') not in ('', '0')
-_side = {}
-
-
-def _side_stream(device):
-    s = _side.get(device)
-    if s is None:
-        s = _side[device] = torch.cuda.Stream(device=device)
-    return s
 
 
 class _DecoderBCE(torch.autograd.Function):
@@ -217,33 +175,21 @@ class _DecoderBCE(torch.autograd.Function):
         d = torch.empty(n * 196, 64, device=dev)
         g_loss = g_loss.contiguous().float()
         # pass 1: dW4, db4 and the BatchNorm-backward sums of layer 3 (the masked gradient itself is not stored)
-        if DEC_LINSUMS:
-            # by linearity in dlogit: two contractions over the pixels, no gradient tile (csrc/decoder_ops.hip)
-            L = lib.cmvae_dec_out_bwd_sums_partial_len()
-            part = torch.empty(lib.cmvae_dec_out_bwd_sums_grid(n), L, device=dev)
-            tot_lin = torch.empty(L, device=dev)
-            tot = torch.empty(lib.cmvae_dec_out_bwd_partial_len(), device=dev)
-            check(lib.cmvae_dec_out_bwd_sums(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
-                                             _p(g_loss), 1.0, _p(part), _p(tot_lin), _p(tot), _stream()),
-                  'cmvae_dec_out_bwd_sums')
-        else:
-            L = lib.cmvae_dec_out_bwd_partial_len()
-            part = torch.empty(lib.cmvae_dec_out_grid(n), L, device=dev)
-            check(lib.cmvae_dec_out_bwd(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
-                                        _p(g_loss), 1.0, None, _p(part), _stream()), 'cmvae_dec_out_bwd')
-            tot = colsum(part)
+        # by linearity in dlogit: two contractions over the pixels, no gradient tile (csrc/decoder_ops.hip)
+        L = lib.cmvae_dec_out_bwd_sums_partial_len()
+        part = torch.empty(lib.cmvae_dec_out_bwd_sums_grid(n), L, device=dev)
+        tot_lin = torch.empty(L, device=dev)
+        tot = torch.empty(lib.cmvae_dec_out_bwd_partial_len(), device=dev)
+        check(lib.cmvae_dec_out_bwd_sums(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
+                                         _p(g_loss), 1.0, _p(part), _p(tot_lin), _p(tot), _stream()),
+              'cmvae_dec_out_bwd_sums')
         dw4 = tot[:1024].reshape(64, 1, 4, 4)
         db4 = tot[1152:1153]
         sums = tot[1024:1152]
         grads_w, grads_b, grads_g, grads_be = [None] * 3, [None] * 3, [None] * 3, [None] * 3
-        # Per layer: data gradient, BatchNorm backward of the layer below (sums, finalize, apply), weight gradient.
-        # CMVAE_BN_SIDE=1 puts the memory-bound BatchNorm passes on a side stream in the shadow of the weight-gradient
-        # GEMMs.  In isolation half of such a pass hides behind them (tools/probe_overlap.py: 3.18 -> 2.62 ms for four
-        # passes next to four layer-3 launches); inside the step the fork / join events and the slower GEMMs cost more
-        # than the two short passes give back (14.1 -> 14.5 ms/step), and the weight gradients next to the whole
-        # data-gradient chain are worse (14.8: two GEMMs side by side evict each other's operand rows).  Off by default.
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if BN_SIDE_STREAM else None
+        # Per layer: data gradient (with the BatchNorm-backward sums of the layer below from its epilogue), finalize and
+        # apply of that BatchNorm backward, weight gradient of all four phases in one launch.  (Measured and dropped:
+        # the BatchNorm passes on a side stream next to the weight-gradient GEMMs — 14.1 -> 14.5 ms/step.)
         c1, c2, dgamma, dbeta = bn_bwd_finalize(sums, acts[3].shape[0])
         # pass 2 of the last layer's backward writes dy3 directly
         check(lib.cmvae_dec_out_bwd_apply(_p(acts[3]), *(_p(t) for t in folds[3]), _p(w4f), _p(p), _p(tgt), M, n,
@@ -256,45 +202,22 @@ class _DecoderBCE(torch.autograd.Function):
             gd, order = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=PIXEL_MAJOR)
             wtd = ws[li].detach().permute(2, 3, 0, 1).contiguous()   # [ky][kx][ci][co]
             d_in = torch.empty(n * Hi * Hi, 64, device=dev)
-            fused_sums = None
-            if li > 0 and FUSED_BN_SUMS:
-                # the BatchNorm-backward sums of the layer below come out of the data gradient's epilogue
-                fused_sums = conv.conv_gemm_bnbwd(gd, dy, wtd, d_in, x_in, fold_in)      # partials [nblk,128]
-            else:
-                conv.conv_gemm(gd, dy, wtd, d_in)
             dy_below = None
             if li > 0:
-                def bn_below():
-                    if fused_sums is not None:
-                        c1b, c2b, dg, dbe = bn_bwd_sums_finalize(fused_sums, x_in.shape[0])
-                    else:
-                        c1b, c2b, dg, dbe = bn_bwd_finalize(bn_relu_bwd_sums(d_in, x_in, fold_in, masked=False),
-                                                            x_in.shape[0])
-                    grads_g[li - 1], grads_be[li - 1] = dg, dbe
-                    return bn_relu_bwd_apply(d_in, x_in, fold_in, c1b, c2b, False, out=d_in)     # in place
-                if side is None:
-                    dy_below = bn_below()
-                else:
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        dy_below = bn_below()
-                    for t in (grads_g[li - 1], grads_be[li - 1]):
-                        t.record_stream(main)
+                # the BatchNorm-backward sums of the layer below come out of the data gradient's epilogue
+                fused_sums = conv.conv_gemm_bnbwd(gd, dy, wtd, d_in, x_in, fold_in)      # partials [nblk,128]
+                c1b, c2b, grads_g[li - 1], grads_be[li - 1] = bn_bwd_sums_finalize(fused_sums, x_in.shape[0])
+                dy_below = bn_relu_bwd_apply(d_in, x_in, fold_in, c1b, c2b, False, out=d_in)     # in place
+            else:
+                conv.conv_gemm(gd, dy, wtd, d_in)
             dW = torch.empty_like(ws[li])
             db = torch.empty(64, device=dev)
             sc, sh = (fold_in[0], fold_in[1]) if fold_in is not None else (None, None)
             phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=PIXEL_MAJOR)
                       for py in (0, 1) for px in (0, 1)]
-            if MULTI_PHASE:
-                conv.conv_wgrad_multi([g for g, _ in phases], x_in, dy, dW, [t for _, t in phases], s_ci=64 * k * k,
-                                      s_co=k * k, db=db, a_scale=sc, a_shift=sh)
-            else:
-                for i, (g, tap_idx) in enumerate(phases):
-                    conv.conv_wgrad(g, x_in, dy, dW, tap_idx, s_ci=64 * k * k, s_co=k * k, db=db,
-                                    accumulate_db=i > 0, a_scale=sc, a_shift=sh)
+            conv.conv_wgrad_multi([g for g, _ in phases], x_in, dy, dW, [t for _, t in phases], s_ci=64 * k * k,
+                                  s_co=k * k, db=db, a_scale=sc, a_shift=sh)
             grads_w[li], grads_b[li] = dW, db
-            if side is not None and li > 0:
-                main.wait_stream(side)
             d, dy = d_in, dy_below
         d_h = d.reshape(n, 256)
         return (d_h, None, None, None, None,

@@ -8,8 +8,6 @@ pooling argmax from the saved pre-BatchNorm activations.  Layer 1 in training ke
 pre-pooling output is recomputed from the images (nine multiply-adds per value) in the pooling pass and in a
 one-pass backward that gets the conv1 weight gradient by linearity.
 """
-import os
-
 import torch
 
 from . import conv
@@ -17,13 +15,6 @@ from . import dist as _dist
 from ._lib import lib, check
 from .decoder import (colsum, bn_stats_finalize, bn_eval_fold, bn_bwd_sums_finalize, bn_relu_bwd_apply, _p, _stream)
 
-# CMVAE_FUSED_CONV1_APPLY=0: layer 1's BatchNorm-backward apply as a pass of its own (A/B measurements)
-FUSED_CONV1_APPLY = os.environ.get('CMVAE_FUSED_CONV1_APPLY', '1') not in ('', '0')
-# CMVAE_CONV1_LINSUMS=0: layer 1's pooling backward writes dybn and the weight gradient reads it back (A/B measurements)
-CONV1_LINSUMS = os.environ.get('CMVAE_CONV1_LINSUMS', '1') not in ('', '0')
-# CMVAE_CONV1_RECOMPUTE=0: the training step stores layer 1's pre-pooling activation y1 (241 MB at 1200 images) instead
-# of recomputing it from the images in the pooling pass and in the backward pass (needs CONV1_LINSUMS)
-CONV1_RECOMPUTE = os.environ.get('CMVAE_CONV1_RECOMPUTE', '1') not in ('', '0')
 _SIZES = (28, 14, 7, 4)          # conv input sizes; pooled outputs are 14, 7, 4, 2
 TAPS = None                      # tests set this to a dict: receives the pre-BatchNorm outputs and folds of a forward
 
@@ -49,7 +40,7 @@ class _Encoder(torch.autograd.Function):
                                                    _p(fold[1]), n, H, H, _p(a), _stream()), 'cmvae_enc_conv1_pool_fwd')
                 ys.append(None); folds.append(fold); pooled.append(a)
                 continue
-            if li == 0 and training and CONV1_RECOMPUTE and CONV1_LINSUMS:
+            if li == 0:
                 # y1 is never stored: batch statistics from a pass that only sums, then conv1 + BatchNorm + ReLU +
                 # pooling in one pass (the evaluation kernel with the batch fold); the backward recomputes y1 too
                 part = torch.empty(lib.cmvae_rowpass_grid(rows), 128, device=dev)
@@ -68,15 +59,8 @@ class _Encoder(torch.autograd.Function):
                 ys.append(y); folds.append(fold); pooled.append(a)
                 continue
             y = torch.empty(rows, 64, device=dev)
-            part = None
-            if li == 0:
-                if training:
-                    part = torch.empty(lib.cmvae_rowpass_grid(rows), 128, device=dev)
-                check(lib.cmvae_enc_conv1_fwd(_p(x), _p(w1.detach().reshape(64, 9)), _p(b1.detach()), n, H, H, _p(y),
-                                              _p(part), _stream()), 'cmvae_enc_conv1_fwd')
-            else:
-                wt = ws[li].detach().permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous()      # [tap][co][ci]
-                part = conv.conv_gemm(conv.geom_conv3x3(n, H, H), a, wt, y, bias=bs[li].detach(), stats=training)
+            wt = ws[li].detach().permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous()      # [tap][co][ci]
+            part = conv.conv_gemm(conv.geom_conv3x3(n, H, H), a, wt, y, bias=bs[li].detach(), stats=training)
             if training:
                 fold = bn_stats_finalize(part, rows * world, bns[li])
             else:
@@ -85,7 +69,6 @@ class _Encoder(torch.autograd.Function):
             check(lib.cmvae_pool_fwd(_p(y), _p(fold[0]), _p(fold[1]), n, H, H, _p(a), _stream()), 'cmvae_pool_fwd')
             ys.append(y); folds.append(fold); pooled.append(a)
         ctx.training, ctx.n = training, n
-        ctx.recompute = bool(training and CONV1_RECOMPUTE and CONV1_LINSUMS)      # y1 was not stored
         ctx.ys, ctx.folds, ctx.pooled = ys, folds, pooled
         if TAPS is not None:
             TAPS['enc'] = (ys, folds)
@@ -107,22 +90,17 @@ class _Encoder(torch.autograd.Function):
             Ho = (H + 1) // 2
             rows = n * H * H
             y, fold = ys[li], folds[li]
-            if li == 0 and (CONV1_LINSUMS or ctx.recompute):
-                # the weight gradient is linear in dybn and xhat: one pass over y accumulates everything, dybn is
-                # never written (cmvae_enc_conv1_bwd_lin); c1, c2 enter in the finalize
+            if li == 0:
+                # the weight gradient is linear in dybn and xhat: one pass that recomputes y1 from the images
+                # accumulates everything, dybn is never written (cmvae_enc_conv1_bwd_lin_rc); c1, c2 enter in the
+                # finalize
                 part_m = torch.empty(256, 64, device=dev)
                 check(lib.cmvae_enc_conv1_tap_sums(_p(x), n, H, H, _p(part_m), _stream()), 'cmvae_enc_conv1_tap_sums')
-                if ctx.recompute:
-                    part = torch.empty(lib.cmvae_enc_conv1_bwd_lin_rc_grid(n), lib.cmvae_enc_conv1_bwd_lin_cols(),
-                                       device=dev)
-                    check(lib.cmvae_enc_conv1_bwd_lin_rc(_p(d), _p(x), _p(w1.detach().reshape(64, 9)), _p(b1.detach()),
-                                                         *(_p(t) for t in fold), _p(part_m), n, H, H, _p(part),
-                                                         _stream()), 'cmvae_enc_conv1_bwd_lin_rc')
-                else:
-                    part = torch.empty(lib.cmvae_rowpass_grid(n * Ho * Ho), lib.cmvae_enc_conv1_bwd_lin_cols(),
-                                       device=dev)
-                    check(lib.cmvae_enc_conv1_bwd_lin(_p(d), _p(y), _p(x), *(_p(t) for t in fold), _p(part_m), n, H, H,
-                                                      _p(part), _stream()), 'cmvae_enc_conv1_bwd_lin')
+                part = torch.empty(lib.cmvae_enc_conv1_bwd_lin_rc_grid(n), lib.cmvae_enc_conv1_bwd_lin_cols(),
+                                   device=dev)
+                check(lib.cmvae_enc_conv1_bwd_lin_rc(_p(d), _p(x), _p(w1.detach().reshape(64, 9)), _p(b1.detach()),
+                                                     *(_p(t) for t in fold), _p(part_m), n, H, H, _p(part),
+                                                     _stream()), 'cmvae_enc_conv1_bwd_lin_rc')
                 tot = colsum(part)
                 sums_glob = _dist.global_sums(tot[:128])
                 dW, gb[0], gg[0], gbe[0] = (torch.empty(k, device=dev) for k in (576, 64, 64, 64))
@@ -138,29 +116,15 @@ class _Encoder(torch.autograd.Function):
             check(lib.cmvae_pool_bwd(_p(d), _p(y), *(_p(t) for t in fold), n, H, H, _p(dybn), _p(part), _stream()),
                   'cmvae_pool_bwd')
             c1, c2, gg[li], gbe[li] = bn_bwd_sums_finalize(part, rows)
-            if li == 0 and FUSED_CONV1_APPLY:
-                # conv1's gradient feeds its weight gradient only: the BatchNorm-backward apply happens on that load
-                part = torch.empty(lib.cmvae_rowpass_grid(rows), 640, device=dev)
-                check(lib.cmvae_enc_conv1_wgrad_bn(_p(x), _p(dybn), _p(y), _p(fold[0]), _p(fold[2]), _p(fold[3]), _p(c1),
-                                                   _p(c2), n, H, H, _p(part), _stream()), 'cmvae_enc_conv1_wgrad_bn')
-                tot = colsum(part)
-                gw[0], gb[0] = tot[:576].reshape(64, 1, 3, 3), tot[576:640]
-                continue
             dy = bn_relu_bwd_apply(dybn, y, fold, c1, c2, True, out=dybn)
-            if li > 0:
-                a_in = pooled[li - 1]
-                dW = torch.empty_like(ws[li])
-                db = torch.empty(64, device=dev)
-                conv.conv_wgrad(conv.geom_conv3x3(n, H, H), a_in, dy, dW, list(range(9)), s_ci=9, s_co=576, db=db)
-                gw[li], gb[li] = dW, db
-                wtd = ws[li].detach().permute(2, 3, 1, 0).reshape(9, 64, 64).contiguous()     # [tap][ci][co]
-                d = torch.empty(rows, 64, device=dev)
-                conv.conv_gemm(conv.geom_conv3x3(n, H, H, transpose=True), dy, wtd, d)
-            else:
-                part = torch.empty(lib.cmvae_rowpass_grid(rows), 640, device=dev)
-                check(lib.cmvae_enc_conv1_wgrad(_p(x), _p(dy), n, H, H, _p(part), _stream()), 'cmvae_enc_conv1_wgrad')
-                tot = colsum(part)
-                gw[0], gb[0] = tot[:576].reshape(64, 1, 3, 3), tot[576:640]
+            a_in = pooled[li - 1]
+            dW = torch.empty_like(ws[li])
+            db = torch.empty(64, device=dev)
+            conv.conv_wgrad(conv.geom_conv3x3(n, H, H), a_in, dy, dW, list(range(9)), s_ci=9, s_co=576, db=db)
+            gw[li], gb[li] = dW, db
+            wtd = ws[li].detach().permute(2, 3, 1, 0).reshape(9, 64, 64).contiguous()     # [tap][ci][co]
+            d = torch.empty(rows, 64, device=dev)
+            conv.conv_gemm(conv.geom_conv3x3(n, H, H, transpose=True), dy, wtd, d)
         out = [None, None, None]
         for li in range(4):
             out += [gw[li], gb[li], gg[li], gbe[li]]

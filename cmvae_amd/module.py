@@ -11,7 +11,6 @@ Unlike the reference nothing here calls ``.cuda()``: modules are built on the CP
 with ``.to(device)``.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -19,10 +18,6 @@ import torch.nn as nn
 from . import dist as _dist
 from .linear import linear as _linear, causal_mlp as _causal_mlp, attention as _attention, \
     self_attention as _self_attention
-
-# CMVAE_FUSED_QKV=0: fc_q, fc_k, fc_v of the self-attention blocks as three GEMMs (A/B measurements)
-FUSED_QKV = os.environ.get('CMVAE_FUSED_QKV', '1') not in ('', '0')
-
 
 class EpisodeBatchNorm2d(nn.BatchNorm2d):
     """Parameters and running statistics of a BatchNorm2d whose training statistics span the whole
@@ -95,7 +90,7 @@ class MAB(nn.Module):
         self.fc_o = nn.Linear(dim_V, dim_V)
 
     def forward(self, Q, K):
-        if Q is K and Q.dim() == 3 and Q.shape[0] * Q.shape[1] > 0 and FUSED_QKV:
+        if Q is K and Q.dim() == 3 and Q.shape[0] * Q.shape[1] > 0:
             # self-attention: the three projections read the same rows -> one GEMM over the stacked weights
             o = _self_attention(Q, self.fc_q.weight, self.fc_q.bias, self.fc_k.weight, self.fc_k.bias,
                                 self.fc_v.weight, self.fc_v.bias, self.num_heads, 1.0 / math.sqrt(self.dim_V))

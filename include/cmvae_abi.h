@@ -374,24 +374,17 @@ int cmvae_dec_out_bwd_apply(const float* y3, const float* scale, const float* sh
 
 /* ==== OmniglotEncoder pieces that are not 64->64 GEMMs (omniglot/module.py:12-33)
  * Conv2d(1,64,3,1,1): x [n,H,W] -> y [n*H*W,64]; w [64,9]; stats_part (optional)
- * [cmvae_rowpass_grid(n*H*W)][128].  wgrad: part [cmvae_rowpass_grid(n*H*W)][640] = {dW[64][9], db[64]}.
+ * [cmvae_rowpass_grid(n*H*W)][128] (y may be NULL: statistics only).
  * pool: relu(bn(y)) then MaxPool2d(2, ceil_mode=True): y [n,H,W,64] -> out [n,ceil(H/2),ceil(W/2),64];
  * bwd: d_pool -> dybn [n,H,W,64] (first maximum takes the gradient, ReLU mask applied) and
  * part [cmvae_rowpass_grid(n*Ho*Wo)][128] = {sum dybn, sum dybn*xhat}.                            */
 int cmvae_enc_conv1_fwd(const float* x, const float* w, const float* b, int n, int H, int W,
                         float* y, float* stats_part, void* stream);
-int cmvae_enc_conv1_wgrad(const float* x, const float* dy, int n, int H, int W, float* part, void* stream);
-/* The same straight from the masked gradient dybn and the pre-BatchNorm output y of layer 1, with the
- * BatchNorm-backward apply dy = scale * (dybn - c1 - (y - mean) * invstd * c2) on the load: conv1's gradient has no
- * other consumer, so the apply pass is never run for it.                                                       */
-int cmvae_enc_conv1_wgrad_bn(const float* x, const float* dybn, const float* y, const float* scale, const float* mean,
-                             const float* invstd, const float* c1, const float* c2, int n, int H, int W, float* part,
-                             void* stream);
-/* Layer 1's whole backward (autograd of omniglot/module.py:14-17 for the first conv block) in one pass over y: the
+/* Layer 1's whole backward (autograd of omniglot/module.py:14-17 for the first conv block) in one pass: the
  * weight gradient is linear in dybn and xhat, so the pooling backward accumulates per channel s1 = sum dybn,
  * s2 = sum dybn*xhat, P1[t] = sum dybn*(x_t - m_t) and never writes dybn; m_t = mean of tap t of the images (zero
  * padding included).  cmvae_enc_conv1_tap_sums: part_m [256][64] = partial {sum x_t [9], sum x_t'*x_t [45, t' <= t]}.
- * part [cmvae_rowpass_grid(n*Ho*Wo)][cmvae_enc_conv1_bwd_lin_cols()]: {s1, s2}[64], P1 [64][9].
+ * part [cmvae_enc_conv1_bwd_lin_rc_grid(n)][cmvae_enc_conv1_bwd_lin_cols()]: {s1, s2}[64], P1 [64][9].
  * cmvae_enc_conv1_lin_finalize: tot = column sums of part (this rank), sums_glob [128] = {s1, s2} summed over the
  * ranks (tot itself in one process), count_glob = values per channel over all ranks, w [64][9], b [64] = conv1;
  * sum xhat*(x_t - m_t) = invstd_c * sum_t' w[c][t'] Gc[t'][t] (Gc: Gram matrix of the centred taps) and
@@ -400,10 +393,7 @@ int cmvae_enc_conv1_wgrad_bn(const float* x, const float* dybn, const float* y, 
  *   dgamma = s2, dbeta = s1,  c1 = sums_glob[c]/count_glob, c2 = sums_glob[64+c]/count_glob, N = n*H*W.            */
 int cmvae_enc_conv1_bwd_lin_cols(void);
 int cmvae_enc_conv1_tap_sums(const float* x, int n, int H, int W, float* part_m, void* stream);
-int cmvae_enc_conv1_bwd_lin(const float* d_pool, const float* y, const float* x, const float* scale, const float* shift,
-                            const float* mean, const float* invstd, const float* part_m, int n, int H, int W, float* part,
-                            void* stream);
-/* cmvae_enc_conv1_bwd_lin with y recomputed from the images (the arithmetic of cmvae_enc_conv1_fwd, bit for bit): the
+/* The pass itself, with y recomputed from the images (the arithmetic of cmvae_enc_conv1_fwd, bit for bit): the
  * training step then never stores layer 1's pre-pooling activation (cmvae_enc_conv1_fwd with y = NULL for the batch
  * statistics, cmvae_enc_conv1_pool_fwd with the batch fold for the pooled output).
  * part [cmvae_enc_conv1_bwd_lin_rc_grid(n)][cmvae_enc_conv1_bwd_lin_cols()].                                       */

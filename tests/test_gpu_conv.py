@@ -282,89 +282,46 @@ def test_dec_out_backward_sums_by_linearity(device, n, M):
         assert rel_err(got[sl], want[sl]) < 2e-5, sl
 
 
-def test_conv1_weight_gradient_with_the_bn_apply_on_its_load(device):
-    """Encoder layer 1: the BatchNorm-backward apply fused into the conv1 weight-gradient load gives the gradients of
-    the separate apply pass + weight gradient (same arithmetic per element, same summation order)."""
-    from cmvae_amd import encoder
-    from cmvae_amd.module import OmniglotEncoder
-    torch.manual_seed(3)
-    enc = OmniglotEncoder(64).to(device).train()
-    x = (torch.rand(48, 784, device=device) < 0.2).float()
-    gh = torch.randn(48, 256, device=device)
-    grads = []
-    lin = encoder.CONV1_LINSUMS
-    encoder.CONV1_LINSUMS = False
-    try:
-        for flag in (True, False):
-            encoder.FUSED_CONV1_APPLY = flag
-            try:
-                enc.zero_grad(set_to_none=True)
-                encoder.encode_images(enc, x).backward(gh)
-            finally:
-                encoder.FUSED_CONV1_APPLY = True
-            grads.append([p.grad.clone() for p in enc.parameters()])
-    finally:
-        encoder.CONV1_LINSUMS = lin
-    scale = max(float(t.abs().max()) for t in grads[1])
-    for a, b in zip(*grads):
-        # (a conv bias in front of a BatchNorm has a zero gradient: what both sides hold there is rounding noise,
-        # so the bar is absolute, on the scale of the other gradients)
-        assert torch.equal(a, b) or rel_err(a, b) < 1e-6 or float((a - b).abs().max()) < 1e-6 * scale
-
-
 @pytest.mark.parametrize('n', [48, 1200])
 def test_conv1_backward_in_one_pass_by_linearity(device, n):
-    """Encoder layer 1: sums of dybn, xhat and their products with the centred taps, c1 and c2 put in afterwards,
-    against the pooling backward that writes dybn + the weight gradient that reads it back, and against fp64 autograd
-    of the same block (omniglot/module.py:14-17)."""
+    """Encoder layer 1 in training: no activation is stored (batch statistics from a summing pass, pooled output from
+    the evaluation kernel with the batch fold) and the backward is ONE pass that recomputes y1 from the images and gets
+    the conv1 weight gradient by linearity — sums of dybn, xhat and their products with the centred taps, c1 and c2 put
+    in afterwards (cmvae_enc_conv1_bwd_lin_rc, cmvae_enc_conv1_lin_finalize).  Against float64 autograd of the whole
+    encoder (omniglot/module.py:12-33): output, and every parameter gradient."""
     from cmvae_amd import encoder
     from cmvae_amd.module import OmniglotEncoder
     torch.manual_seed(5)
     enc = OmniglotEncoder(64).to(device).train()
     x = (torch.rand(n, 784, device=device) < 0.2).float()
     gh = torch.randn(n, 256, device=device)
-    grads, outs = [], []
-    lin, rc = encoder.CONV1_LINSUMS, encoder.CONV1_RECOMPUTE
-    try:
-        # one pass with y1 recomputed from the images (the default), one pass over the stored y1, the two-pass path
-        for flag, recompute in ((True, True), (True, False), (False, False)):
-            encoder.CONV1_LINSUMS, encoder.CONV1_RECOMPUTE = flag, recompute
-            enc.zero_grad(set_to_none=True)
-            h = encoder.encode_images(enc, x)
-            h.backward(gh)
-            outs.append(h.detach().clone())
-            grads.append([p.grad.clone() for p in enc.parameters()])
-    finally:
-        encoder.CONV1_LINSUMS, encoder.CONV1_RECOMPUTE = lin, rc
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])      # the recomputed y1 is the stored one
-    scale = max(float(t.abs().max()) for t in grads[2])
-    names = [k for k, _ in enc.named_parameters()]
-    # (the two one-pass variants sum the same terms over different partitions of the windows)
-    for other, tol in ((grads[1], 2e-6), (grads[2], 2e-5)):
-        for k, a, b in zip(names, grads[0], other):
-            if k in ('encoder.0.bias', 'encoder.4.bias', 'encoder.8.bias', 'encoder.12.bias'):
-                # a conv bias in front of a BatchNorm has a zero gradient: both sides hold rounding noise around zero
-                assert float(a.abs().max()) < 3e-5 * scale and float(b.abs().max()) < 3e-5 * scale, k
-            else:
-                assert torch.equal(a, b) or rel_err(a, b) < tol, k
-    # fp64 autograd of the whole encoder on the CPU
+    h_hip = encoder.encode_images(enc, x)
+    h_hip.backward(gh)
+    # float64 autograd of the whole encoder on the CPU
     h = x.double().cpu().view(n, 1, 28, 28)
-    w1 = None
+    ref = {}
     for i in range(4):
         cv, bn = enc.encoder[4 * i], enc.encoder[4 * i + 1]
-        w = cv.weight.detach().double().cpu().requires_grad_(i == 0)
-        w1 = w if i == 0 else w1
-        h = F.conv2d(h, w, cv.bias.detach().double().cpu(), padding=1)
-        h = F.batch_norm(h, None, None, bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu(), True, 0.1,
-                         bn.eps)
+        for name, t in (('%d.weight' % (4 * i), cv.weight), ('%d.bias' % (4 * i), cv.bias),
+                        ('%d.weight' % (4 * i + 1), bn.weight), ('%d.bias' % (4 * i + 1), bn.bias)):
+            ref[name] = t.detach().double().cpu().requires_grad_(True)
+        h = F.conv2d(h, ref['%d.weight' % (4 * i)], ref['%d.bias' % (4 * i)], padding=1)
+        h = F.batch_norm(h, None, None, ref['%d.weight' % (4 * i + 1)], ref['%d.bias' % (4 * i + 1)], True, 0.1, bn.eps)
         h = F.max_pool2d(F.relu(h), 2, ceil_mode=True)
-    h.permute(0, 2, 3, 1).reshape(n, 256).backward(gh.double().cpu())                              # channels-last
-    w_ref = w1.grad
-    w_new, w_old = grads[0][0].double().cpu(), grads[2][0].double().cpu()
-    e_new, e_old = rel_err(w_new, w_ref), rel_err(w_old, w_ref)
-    # (at 1200 images a few ReLU / max-pool decisions of the fp32 forward differ from the fp64 one's: both paths then sit
-    # at the same distance from it)
-    assert e_new < 1.05 * e_old + 2e-6 and (n > 48 or e_new < 2e-5), (e_new, e_old)
+    h = h.permute(0, 2, 3, 1).reshape(n, 256)                                   # channels-last
+    h.backward(gh.double().cpu())
+    assert rel_err(h_hip, h) < 1e-5
+    scale = max(float(t.grad.abs().max()) for t in ref.values())
+    # (at 1200 images a few ReLU / max-pool decisions of the fp32 forward differ from the float64 one's: every gradient
+    # upstream of such a unit moves by about 1 / n)
+    tol = 2e-5 if n == 48 else 2e-3
+    for name, p in enc.encoder.named_parameters():
+        g_ref = ref[name].grad
+        if name.endswith('bias') and int(name.split('.')[0]) % 4 == 0:
+            # a conv bias in front of a BatchNorm has a zero gradient: both sides hold rounding noise around zero
+            assert float(p.grad.abs().max()) < 3e-5 * scale, name
+        else:
+            assert rel_err(p.grad, g_ref) < tol, (name, rel_err(p.grad, g_ref))
 
 
 def test_multi_launch_rejects_what_it_cannot_run(device):

@@ -181,15 +181,14 @@ def test_graphed_step_equals_eager_step(device):
     h_lambda, h_c, h_old = 0.1, 0.1, float('inf')
     for _ in range(3):
         out = stepper(batches[0], seeds[0], h_lambda, h_c, 1e-3)
-        rec_, kl_, ha_, h_ = (float(t) for t in out)
-        A = m2.causal.get_w().detach()
+        h_ = float(out[3])
         assert len(stepper.graphs) == 1
         h_lambda, h_c, h_old = dual_ascent_update(h_, h_lambda, h_c, h_old)
     assert h_lambda > 0.1                                    # the schedule did move the constants
-    # the last replay used the constants it was called with (A read after the step: one Adam update of lr 1e-3 away)
+    # the last replay used the constants it was called with (A as it was before the step's Adam update)
+    A = m2.causal.get_w().detach().clone()
     out = stepper(batches[0], seeds[0], h_lambda, h_c, 1e-3)
-    A = m2.causal.get_w().detach()
     h_now = float(out[3])
     assert abs(float(out[2]) - (h_lambda * h_now + 0.5 * h_c * h_now ** 2 + 1e-3 * float(A.abs().sum()))) \
-        <= 2e-2 * abs(float(out[2]))
+        <= 1e-4 * abs(float(out[2]))
     assert len(stepper.graphs) == 1
