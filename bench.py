@@ -518,7 +518,9 @@ def main():
         n_pool = 4
         pool = [synth_batch(cfg, Bl * world, S, 'cpu', 100 + i)[cdist.shard_slice(Bl * world, rank, world)].to(device)
                 for i in range(n_pool)]
-        seeds = cdist.SeedUploader((Bl, way), device)
+        # (a deep ring: the host is never held back by the upload of a step the GPU has not reached yet, so that
+        # host_ms_per_step below is the host's own issue time)
+        seeds = cdist.SeedUploader((Bl, way), device, depth=64)
 
         # what Trainer does (--graph-step auto): the feature models' step, bound by the host's launch rate when issued
         # eagerly, is replayed from a HIP graph (with several ranks: up to the gradient pack); the Omniglot step
@@ -586,6 +588,14 @@ def main():
                    step_ms_rank_max=round(rank_max / args.steps * 1e3, 3),
                    step_ms_rank_min=round(rank_min / args.steps * 1e3, 3),
                    final_losses={'rec': losses[0], 'kl': losses[1], 'h_aug': losses[2]})
+        if graphed is not None:
+            # the same step issued launch by launch (what the graph replaces): bound by the host's launch rate
+            g_keep, graphed = graphed, None
+            for i in range(3):
+                step(i)
+            out['eager_ms_per_step'] = round(timed(args.steps)[0] / args.steps * 1e3, 3)
+            graphed = g_keep
+            note('eager timed region done: %.2f ms/step' % out['eager_ms_per_step'])
         if args.long_steps > args.steps and not REHEARSE:
             dt_long = timed(args.long_steps)[0]
             out['steps_long'] = args.long_steps

@@ -61,6 +61,39 @@ __global__ __launch_bounds__(256) void reparam_logq_bwd_kernel(const float* __re
     dlogvar[(size_t)r * D + lane] = av - 0.5f * ag;
 }
 
+// The same for few rows with many samples each (the feature models: 80 rows x 256 samples — one wave per row walked
+// its 256 samples in a dependent chain for 112 us): NW waves share a row, wave w takes samples w, w + NW, ..., and the
+// partial sums are added in wave order (fixed order: reproducible).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void reparam_logq_bwd_wide_kernel(const float* __restrict__ logvar,
+                                                                        const float* __restrict__ eps,
+                                                                        const float* __restrict__ gz,
+                                                                        const float* __restrict__ glogq, int M,
+                                                                        float* __restrict__ dmean,
+                                                                        float* __restrict__ dlogvar) {
+    __shared__ float red[3][NW][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t r = blockIdx.x;
+    const float hs = 0.5f * expf(0.5f * logvar[r * D + lane]);
+    float am = 0.f, av = 0.f, ag = 0.f;
+    for (int m = w; m < M; m += NW) {
+        const size_t o = (r * M + m) * D + lane;
+        const float g = gz ? gz[o] : 0.f;
+        am += g;
+        av = fmaf(g * eps[o], hs, av);
+        if (glogq) ag += glogq[r * M + m];
+    }
+    red[0][w][lane] = am; red[1][w][lane] = av; red[2][w][lane] = ag;
+    __syncthreads();
+    if (w == 0) {
+        am = av = ag = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { am += red[0][k][lane]; av += red[1][k][lane]; ag += red[2][k][lane]; }
+        dmean[r * D + lane] = am;
+        dlogvar[r * D + lane] = av - 0.5f * ag;
+    }
+}
+
 // ---------------------------------------------------------------- expm trace
 constexpr int XL = 68;
 
@@ -244,6 +277,11 @@ extern "C" int cmvae_reparam_logq_bwd(const float* logvar, const float* eps, con
     CMVAE_REQUIRE(logvar && eps && dmean && dlogvar, "cmvae_reparam_logq_bwd: NULL tensor");
     CMVAE_REQUIRE(rows >= 0 && M > 0, "cmvae_reparam_logq_bwd: bad shape");
     if (rows == 0) return 0;
+    if (M >= 64 && rows <= 4 * compute_units()) {        // few rows, long sample chains: sixteen waves per row
+        hipLaunchKernelGGL(reparam_logq_bwd_wide_kernel<16>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logvar, eps,
+                           gz, glogq, M, dmean, dlogvar);
+        return check_launch("reparam_logq_bwd_wide_kernel");
+    }
     hipLaunchKernelGGL(reparam_logq_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logvar, eps,
                        gz, glogq, rows, M, dmean, dlogvar);
     return check_launch("reparam_logq_bwd_kernel");

@@ -174,14 +174,16 @@ def test_mixture_loglik_fwd_bwd(device, K, N):
     assert rel_err(ld.grad, lr.grad) < 1e-5
 
 
-def test_reparam_logq_fwd_bwd(device):
+@pytest.mark.parametrize('M', [7, 64, 256])
+def test_reparam_logq_fwd_bwd(device, M):
+    """M >= 64 over a few rows: the backward's sixteen-waves-per-row variant (the feature models' 80 rows x 256)."""
     from cmvae_amd import ops
     g = torch.Generator().manual_seed(13)
     mean = torch.randn(3, 5, 64, generator=g)
     lv = torch.randn(3, 5, 64, generator=g) * 0.5
-    eps = torch.randn(3, 5, 7, 64, generator=g)
-    gz = torch.randn(3, 5, 7, 64, generator=g)
-    gq = torch.randn(3, 5, 7, generator=g)
+    eps = torch.randn(3, 5, M, 64, generator=g)
+    gz = torch.randn(3, 5, M, 64, generator=g)
+    gq = torch.randn(3, 5, M, generator=g)
     mr = mean.clone().double().requires_grad_(True)
     lr = lv.clone().double().requires_grad_(True)
     zr = eps.double() * (0.5 * lr).exp()[:, :, None] + mr[:, :, None]
