@@ -470,7 +470,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     ranks_seen = 1
-    if world > 1:
+    multi = cdist.exchanging()                               # several ranks (or CMVAE_DIST_FORCE=1 on one)
+    if multi:
         t = torch.ones(1, device=device)
         cdist.all_reduce(t, 'ranks_seen')                     # the ranks RCCL actually connects
         ranks_seen = int(t.item())
@@ -489,7 +490,7 @@ def main():
     torch.manual_seed(10086)                                       # every rank alike, as main.py seeds them
 
     def barrier():
-        if world > 1:
+        if multi:
             torch.distributed.barrier()
 
     def note(msg):
@@ -497,7 +498,7 @@ def main():
             print('[bench %7.1fs] %s' % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     def max_over_ranks(dt):
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             cdist.all_reduce(t, 'max_over_ranks', op=torch.distributed.ReduceOp.MAX)
             return float(t)
@@ -526,7 +527,7 @@ def main():
         # eagerly, is replayed from a HIP graph (with several ranks: up to the gradient pack); the Omniglot step
         # stays eager
         graphed = None
-        if (args.graph_step == 'on' and (world == 1 or cfg['variant'] != 'omniglot')) or \
+        if (args.graph_step == 'on' and (not multi or cfg['variant'] != 'omniglot')) or \
                 (args.graph_step == 'auto' and cfg['variant'] != 'omniglot'):
             from cmvae_amd.graph_step import GraphedStep
             graphed = GraphedStep(model, flat, opt)      # several ranks: the exchange and Adam follow the replay
@@ -543,7 +544,7 @@ def main():
             flat.zero()
             X = pool[i % n_pool]
             idx = seeds.upload(cdist.draw_em_init(N, way, Bl * world, rank, world, prefetch=True))
-            eps = cdist.draw_eps(Bl * world, S, M, 64, device, rank, world) if world > 1 else None
+            eps = cdist.draw_eps(Bl * world, S, M, 64, device, rank, world) if multi else None
             _, rec, kl, h_aug, _ = model(X, h_lambda, h_c, a_lambda, eps=eps, init_idx=idx)
             (rec + kl + h_aug).backward()
             flat.allreduce()
@@ -551,7 +552,7 @@ def main():
             return rec, kl, h_aug
 
         def min_over_ranks(dt):
-            if world > 1:
+            if multi:
                 t = torch.tensor([dt], device=device, dtype=torch.float64)
                 cdist.all_reduce(t, 'min_over_ranks', op=torch.distributed.ReduceOp.MIN)
                 return float(t)
@@ -563,9 +564,14 @@ def main():
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            marks = []
             for i in range(n_steps):
                 last = step(i)
-            t_issued = time.perf_counter() - t0
+                marks.append(time.perf_counter())
+            # the host's own issue time per step: the first steps after the synchronize, while the launch queue is still
+            # shallow (later the runtime holds the host back to the GPU's pace and the loop time says nothing)
+            k = min(3, n_steps)
+            t_issued = (marks[k - 1] - t0) / k * n_steps
             torch.cuda.synchronize()
             t_rank = time.perf_counter() - t0          # this rank's own step time, before it waits for the others
             barrier()
@@ -582,8 +588,8 @@ def main():
         note('timed region done: %.2f ms/step' % (dt / args.steps * 1e3))
         out.update(value=round(Bl * world * args.steps / dt, 3), unit='train episodes/s',
                    ms_per_step=round(dt / args.steps * 1e3, 3),
-                   # host_ms_per_step: wall time of the loop that issues the steps, before any wait for the GPU (the
-                   # launches are asynchronous; a value near ms_per_step means the job is bound by the host)
+                   # host_ms_per_step: what the host needs to issue one step (launches are asynchronous; a value near
+                   # ms_per_step means the job is bound by the host)
                    host_ms_per_step=round(t_host / args.steps * 1e3, 3),
                    step_ms_rank_max=round(rank_max / args.steps * 1e3, 3),
                    step_ms_rank_min=round(rank_min / args.steps * 1e3, 3),
@@ -686,7 +692,7 @@ def main():
     if REHEARSE:
         import faulthandler
         faulthandler.cancel_dump_traceback_later()
-    if world > 1:
+    if multi:
         torch.distributed.destroy_process_group()
 
 

@@ -58,7 +58,7 @@ def bn_stats_finalize(part, count, bn):
     """Training-mode fold (scale, shift, mean, invstd) from the conv GEMM's partial statistics [nblk,128]; count =
     values per channel over ALL ranks.  One process: one launch (sums, finalize, running statistics and the batch
     counter); several: column sums, all-reduce (collective C2), finalize."""
-    if _dist.world_size() > 1 or bn.momentum is None:
+    if _dist.exchanging() or bn.momentum is None:
         return bn_finalize(_global_sums(colsum(part)), count, bn)
     dev = part.device
     scale, shift, mean, invstd = (torch.empty(64, device=dev) for _ in range(4))
@@ -73,7 +73,7 @@ def bn_stats_finalize(part, count, bn):
 def bn_bwd_sums_finalize(part, count):
     """(c1, c2, dgamma, dbeta) from partial BatchNorm-backward sums [nblk,128]; count = this rank's values per
     channel."""
-    if _dist.world_size() > 1:
+    if _dist.exchanging():
         return bn_bwd_finalize(colsum(part), count)
     dev = part.device
     c1, c2, dgamma, dbeta = (torch.empty(64, device=dev) for _ in range(4))

@@ -82,11 +82,27 @@ def rank():
     return tdist.get_rank() if is_dist() else 0
 
 
+# CMVAE_DIST_FORCE=1: a ONE-rank job walks the several-ranks code (process group, BatchNorm-statistics and gradient
+# exchanges, the hook-issued tail bucket, the sharded noise draw) — how the RCCL path is exercised on a one-GPU box:
+# an all-reduce over one rank is the identity, but the process group, its streams and its interplay with hooks and HIP
+# graph capture are the real ones (tests/test_gpu_dist.py, `CMVAE_DIST_FORCE=1 python bench.py`)
+_FORCE = os.environ.get('CMVAE_DIST_FORCE', '') == '1'
+
+
+def exchanging():
+    """True when the step exchanges BatchNorm statistics and gradients: several ranks (or CMVAE_DIST_FORCE)."""
+    return world_size() > 1 or (_FORCE and is_dist())
+
+
 def init_from_env(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1 or is_dist():
+    if (ws <= 1 and not _FORCE) or is_dist():
         return rank(), world_size()
+    if ws <= 1:                                      # CMVAE_DIST_FORCE: a process group of one
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('MASTER_PORT', '29533')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if torch.cuda.is_available():
@@ -254,7 +270,7 @@ def global_sums(sums):
     sum dy*xhat} in the backward pass; 128 floats) summed over the ranks.  The one implementation of the exchange:
     the HIP pipelines (cmvae_amd/encoder.py, decoder.py) and the CPU restatement the gloo tests run
     (tests/sync_bn_reference.py) both call it."""
-    if world_size() > 1:
+    if exchanging():
         g = sums.clone()
         all_reduce(g, 'bn_sums')
         return g
@@ -300,7 +316,7 @@ class FlatGrads:
         n_tail_params = max(0, min(int(n_tail_params), len(self.params)))
         self._tail_start = len(self.params) - n_tail_params
         self._tail_off = sum(p.numel() for p in self.params[:self._tail_start]) if n_tail_params else self.flat.numel()
-        if n_tail_params and world_size() > 1:
+        if n_tail_params and exchanging():
             for p in self.params[self._tail_start:]:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._tail_hook))
         return self
@@ -343,14 +359,14 @@ class FlatGrads:
         """Mean over ranks of the packed buffer, one all-reduce of everything (for callers that pack elsewhere — the
         HIP-graph step packs inside the graph and exchanges after the replay)."""
         ws = world_size()
-        if ws > 1:
+        if exchanging():
             all_reduce(self.flat, 'grad_all')
             self.flat.div_(ws)
 
     def allreduce(self):
         """Gather the gradients, then mean over ranks (every loss term is a mean over equal-sized shards)."""
         ws = world_size()
-        if ws == 1:
+        if not exchanging():
             self.pack()
             return
         if self._tail_done:

@@ -31,7 +31,8 @@ class GraphedStep:
             raise RuntimeError('cmvae_amd: GraphedStep needs the model on the GPU (there is no CPU path)')
         optimizer.device_step()
         self.world, self.rank = cdist.world_size(), cdist.rank()
-        if self.world > 1:
+        self.exchanging = cdist.exchanging()
+        if self.exchanging:
             flat.overlap_tail(0)
         self.calls = 0
         self.graphs = {}            # shapes -> (consts, graph, X, idx, eps, outputs)
@@ -42,19 +43,19 @@ class GraphedStep:
         _, rec, kl, h_aug, h = self.model(X, *consts, eps=eps, init_idx=idx)
         (rec + kl + h_aug).backward()
         self.flat.pack()
-        if self.world == 1:
+        if not self.exchanging:
             self.optimizer.step()
         return rec.detach(), kl.detach(), h_aug.detach(), h.detach()
 
     def _after(self):
         """What follows the graph when the job has several ranks: gradient exchange and update."""
-        if self.world > 1:
+        if self.exchanging:
             self.flat.exchange()
             self.optimizer.step()
 
     def _draw(self, shape, out=None):
         """The step's reparametrisation noise, by the same generator calls as the eager step."""
-        if self.world == 1:
+        if not self.exchanging:
             if out is None:
                 return torch.randn(shape, device=self.device, dtype=torch.float32)
             return torch.randn(shape, out=out)

@@ -111,7 +111,7 @@ class Trainer(object):
                 self._graphed = GraphedStep(self.model, self.flat, self.optimizer)
             return self._graphed(X.contiguous(), idx, h_lambda, h_c, a_lambda)
         eps = None
-        if self.world > 1:
+        if cdist.exchanging():
             # every rank holds the same generator state: draw the global noise and keep this rank's episodes
             eps = cdist.draw_eps(a.batch_size, a.sample_size, a.train_mc_sample_size, a.latent_size, self.device,
                                  self.rank, self.world)
@@ -126,7 +126,7 @@ class Trainer(object):
         bound by its kernels and exchanges BatchNorm statistics inside the step: cmvae_amd/graph_step.py); on / off
         force it (on: single process only for Omniglot)."""
         mode = getattr(self.args, 'graph_step', 'auto')
-        if mode == 'off' or (self.world > 1 and self.variant == 'omniglot') or getattr(self.args, 'debug', False) \
+        if mode == 'off' or (cdist.exchanging() and self.variant == 'omniglot') or getattr(self.args, 'debug', False) \
                 or ops.CHECK_INDICES:
             return False
         return mode == 'on' or self.variant != 'omniglot'

@@ -57,15 +57,18 @@ def _step(model, flat, opt, X, eps, idx, device):
     return torch.stack([rec.detach(), kl.detach(), h_aug.detach()]).cpu(), grads.cpu()
 
 
-def _worker(rank, world, port, out, shape):
+def _worker(rank, world, port, out, shape, backend='gloo'):
     # default hardware queues: the exchanges of GPU tensors over gloo are staged on the calling thread
     # (cmvae_amd/dist.py: _all_reduce; DESIGN.md §5 has the story of the stall this replaced)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK='0')
+    if world == 1:
+        os.environ['CMVAE_DIST_FORCE'] = '1'           # one rank walks the several-ranks code (read at import)
     sh = SHAPES[shape]
     from cmvae_amd import dist as cdist
     from cmvae_amd.linear import FlatAdam
-    cdist.init_from_env('gloo')
+    cdist.init_from_env(backend)
+    assert cdist.exchanging()
     device = torch.device('cuda:0')
     model = _build(device, sh)
     flat = cdist.FlatGrads(model.parameters()).overlap_tail(model.tail_param_count())    # decoder + proj bucket
@@ -138,13 +141,16 @@ def _feat_batches():
     return [torch.relu(torch.randn(FB, FS, FD, generator=g)) for _ in range(FSTEPS)]
 
 
-def _graph_worker(rank, world, port, out):
+def _graph_worker(rank, world, port, out, backend='gloo'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK='0')
+    if world == 1:
+        os.environ['CMVAE_DIST_FORCE'] = '1'
     from cmvae_amd import dist as cdist
     from cmvae_amd.graph_step import GraphedStep
     from cmvae_amd.linear import FlatAdam
-    cdist.init_from_env('gloo')
+    cdist.init_from_env(backend)
+    assert cdist.exchanging()
     device = torch.device('cuda:0')
     model = _feat_model(device)
     flat = cdist.FlatGrads(model.parameters()).overlap_tail(model.tail_param_count())
@@ -201,3 +207,42 @@ def test_two_ranks_graphed_feature_step_equals_one_process(device):
     print('  weights after %d steps: median |d| %.1e, 99th percentile %.1e, max %.1e'
           % (FSTEPS, float(d.median()), float(d.quantile(0.99)), float(d.max())))
     assert float(d.quantile(0.99)) < 1e-4 and float(d.max()) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The production backend on the one GPU of the test box: RCCL ("nccl") refuses two ranks on a device, but a process group
+# of ONE rank with CMVAE_DIST_FORCE=1 walks the whole several-ranks code over it — BatchNorm-statistics all-reduces from
+# the forward and from the autograd thread, the tail bucket all-reduced asynchronously from a gradient hook, the head
+# exchange behind it, the sharded noise draw, and HIP-graph capture next to a live RCCL communicator and its watchdog.
+# An all-reduce over one rank is the identity, so the results must be the plain single-process ones.
+def _single_process_step(device, sh):
+    from cmvae_amd import dist as cdist
+    from cmvae_amd.linear import FlatAdam
+    model = _build(device, sh)
+    flat = cdist.FlatGrads(model.parameters())
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=5e-5)
+    X, eps = _inputs(sh)
+    np.random.seed(21)
+    idx = cdist._draw_em_init_numpy(sh['S'] * sh['M'], sh['K'], sh['B'])
+    losses, grads = _step(model, flat, opt, X, eps, idx, device)
+    return losses, grads, model.proj[0].weight.detach().cpu(), _bn_stats(model)
+
+
+def test_one_rank_over_rccl_walks_the_multi_rank_path(device):
+    sh = SHAPES['tiny']
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(1, _free_port(), out, 'tiny', 'nccl'), nprocs=1, join=True)
+    losses, grads, w, bn = _single_process_step(device, sh)
+    assert torch.allclose(out[0]['losses'], losses, rtol=2e-5, atol=1e-6), (out[0]['losses'], losses)
+    scale = float(grads.abs().max())
+    assert float((out[0]['grads'] - grads).abs().max()) < 2e-4 * scale
+    assert torch.allclose(out[0]['bn'], bn, atol=1e-6, rtol=1e-6)
+
+
+def test_one_rank_over_rccl_graphed_feature_step(device):
+    """The feature models' HIP-graph step with a live RCCL process group: capture, replay, eager all-reduce + Adam."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_graph_worker, args=(1, _free_port(), out, 'nccl'), nprocs=1, join=True)
+    assert out[0]['losses'].shape == (FSTEPS, 4) and bool(torch.isfinite(out[0]['losses']).all())
