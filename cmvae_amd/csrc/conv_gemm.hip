@@ -277,6 +277,54 @@ __device__ __forceinline__ float4 fold_a_scaled_guarded(float4 v, const float4& 
 }
 __device__ __forceinline__ float4 scaled4(const float4& v, float f) { return make_float4(v.x * f, v.y * f, v.z * f, v.w * f); }
 
+// ---------------------------------------------------------------------------- fp32 products on the bf16 matrix pipe
+// An fp32 value is the exact sum of three bf16 pieces, x = x1 + x2 + x3 (round-to-nearest pieces; every residual is
+// exact in fp32).  a * b is then nine exact bf16 x bf16 products, and the six with i + j <= 4 carry everything above
+// 2^-24 |a b| — fp32's own rounding.  v_mfma_f32_32x32x16_bf16 does 16 x the MACs per cycle of the fp32 MFMA, so the
+// six cost 6 / 16 of it; the accumulation is fp32 as before.  Measured (tools/split_mfma_cost.hip, random operands,
+// error against float64 in units of 2^-24 sum|a b|): mean 0.58 / max 7.5 this way, 0.74 / 8.2 with the fp32 MFMA — it
+// is not a reduced-precision path.  The chip lowers its clock under the denser pipe, so the loop gains 1.5 x, not 2.7.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+struct Split3 { unsigned p1, p2, p3; };                  // two values per register: low half = the first one's piece
+__device__ __forceinline__ Split3 split_pair(float x, float y) {
+    Split3 s;
+    s.p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{x, y}, bf16x2));
+    const floatx2 r = floatx2{x, y} - floatx2{__uint_as_float(s.p1 << 16), __uint_as_float(s.p1 & 0xffff0000u)};
+    s.p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    const floatx2 r2 = r - floatx2{__uint_as_float(s.p2 << 16), __uint_as_float(s.p2 & 0xffff0000u)};
+    s.p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+    return s;
+}
+struct Frag3 { uint4 p[3]; };                            // 8 values: three planes of 8 bf16
+__device__ __forceinline__ Frag3 split8(const float4& u, const float4& v) {
+    const Split3 a = split_pair(u.x, u.y), b = split_pair(u.z, u.w), c = split_pair(v.x, v.y), d = split_pair(v.z, v.w);
+    Frag3 f;
+    f.p[0] = make_uint4(a.p1, b.p1, c.p1, d.p1);
+    f.p[1] = make_uint4(a.p2, b.p2, c.p2, d.p2);
+    f.p[2] = make_uint4(a.p3, b.p3, c.p3, d.p3);
+    return f;
+}
+__device__ __forceinline__ bf16x8 as_bf(const uint4& u) { return __builtin_bit_cast(bf16x8, u); }
+__device__ __forceinline__ floatx16 mfma_split6(const Frag3& a, const Frag3& b, floatx16 c) {      // small terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a.p[2]), as_bf(b.p[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a.p[0]), as_bf(b.p[2]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a.p[1]), as_bf(b.p[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a.p[1]), as_bf(b.p[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a.p[0]), as_bf(b.p[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(a.p[0]), as_bf(b.p[0]), c, 0, 0, 0);
+    return c;
+}
+// LDS image of one 64 x 64 weight tile for that path: three planes [64 co][64 ci] of bf16, 128-byte rows.  Channel
+// c = 8 kk + 4 h + j (the lane's operand layout: float4 kk of lane half h) sits at element 16 (kk / 2) + 8 h + 4 (kk & 1)
+// + j, so the 8 channels of MFMA step kk / 2 and lane half h are one 16-byte chunk; chunk q of row co is stored at chunk
+// q ^ ((co >> 1) & 7), which makes the ds_read_b128 of 16 consecutive rows conflict-free without padding (six taps
+// fit 160 KB: 147 456 bytes).
+constexpr int BF3_TAP_BYTES = 3 * 64 * 128;
+__device__ __forceinline__ int bf3_elem(int pl, int co, int chunk) {         // element (bf16) index within a tap
+    return ((pl * 64 + co) * 8 + (chunk ^ ((co >> 1) & 7))) * 8;
+}
+
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {
     if (ACT == 1) return fmaxf(v, 0.f);
@@ -677,7 +725,7 @@ constexpr int WSTAT_TAPS4 = 4, WSTAT_TAPS8 = 9;
 // bid / nblk: the workgroup's index among the workgroups that share this geometry (a launch may run several
 // geometries side by side: conv_gemm_wstat_multi_kernel); stats_bid / stats_nblk: its index in the whole launch.
 // ACCUM: the launch adds to what `out` already holds (the second half of a tap set too large for LDS).
-template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false>
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false, bool BF3 = false>
 __device__ __forceinline__ void wstat_body(
     const ConvGeom& g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
@@ -689,8 +737,10 @@ __device__ __forceinline__ void wstat_body(
     int tiles_done = 0;
 #endif
     extern __shared__ __align__(16) float wstat_smem[];
-    float* Ws = wstat_smem;                                        // [ntaps][64][LDA]
-    int* opix = reinterpret_cast<int*>(Ws + ntaps * 64 * LDA);     // [2][NW waves][32 rows]
+    float* Ws = wstat_smem;                                        // [ntaps][64][LDA]; BF3: [ntaps] bf16 plane images
+    __bf16* Wp = reinterpret_cast<__bf16*>(wstat_smem);
+    int* opix = BF3 ? reinterpret_cast<int*>(reinterpret_cast<char*>(wstat_smem) + (size_t)ntaps * BF3_TAP_BYTES)
+                    : reinterpret_cast<int*>(Ws + ntaps * 64 * LDA);     // [2][NW waves][32 rows]
     float* red = reinterpret_cast<float*>(opix + 2 * NW * 32);     // [NW][128]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -699,10 +749,22 @@ __device__ __forceinline__ void wstat_body(
     {
         const float* Wn = Wt + nb * g.w_nblk_stride + 4 * q;
         for (int t = 0; t < ntaps; ++t)
-            for (int row = rb; row < 64; row += 4 * NW)
-                *reinterpret_cast<float4*>(&Ws[(t * 64 + row) * LDA + 4 * q]) =
-                    scaled4(*reinterpret_cast<const float4*>(Wn + g.w_off[tap0 + t] + (long)row * g.w_pitch),
-                            HAS_T ? FOLD_UP : 1.f);          // the folded operand arrives times 2^-60 (fold_a_scaled)
+            for (int row = rb; row < 64; row += 4 * NW) {
+                const float4 wv = scaled4(*reinterpret_cast<const float4*>(Wn + g.w_off[tap0 + t] + (long)row * g.w_pitch),
+                                          HAS_T ? FOLD_UP : 1.f);    // the folded operand arrives times 2^-60 (fold_a_scaled)
+                if (BF3) {
+                    // channels 4q .. 4q+3 = float4 kk = q / 2 of lane half q & 1: chunk 2 (kk / 2) + (q & 1), elements
+                    // 4 (kk & 1) .. + 3 of it
+                    const Split3 s0 = split_pair(wv.x, wv.y), s1 = split_pair(wv.z, wv.w);
+                    const int kk = q >> 1, chunk = 2 * (kk >> 1) + (q & 1), sub = 4 * (kk & 1);
+                    __bf16* wt = Wp + (size_t)t * (BF3_TAP_BYTES / 2) + sub;
+                    *reinterpret_cast<uint2*>(wt + bf3_elem(0, row, chunk)) = make_uint2(s0.p1, s1.p1);
+                    *reinterpret_cast<uint2*>(wt + bf3_elem(1, row, chunk)) = make_uint2(s0.p2, s1.p2);
+                    *reinterpret_cast<uint2*>(wt + bf3_elem(2, row, chunk)) = make_uint2(s0.p3, s1.p3);
+                } else {
+                    *reinterpret_cast<float4*>(&Ws[(t * 64 + row) * LDA + 4 * q]) = wv;
+                }
+            }
     }
     // BatchNorm fold of this lane's channels (8kk + 4h .. +3)
     float4 sc[HAS_T ? 8 : 1], sh[HAS_T ? 8 : 1];
@@ -824,6 +886,25 @@ __device__ __forceinline__ void wstat_body(
         } else {
             tn = first_tap(rest);
         }
+        if (BF3) {
+            Frag3 fa[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[ks] = split8(a[2 * ks], a[2 * ks + 1]);
+            load_frag(tn);
+            __builtin_amdgcn_sched_barrier(0);
+            const __bf16* wt = Wp + (size_t)t * (BF3_TAP_BYTES / 2);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                Frag3 b0, b1;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    b0.p[pl] = *reinterpret_cast<const uint4*>(wt + bf3_elem(pl, i, 2 * ks + h));
+                    b1.p[pl] = *reinterpret_cast<const uint4*>(wt + bf3_elem(pl, 32 + i, 2 * ks + h));
+                }
+                acc0 = mfma_split6(fa[ks], b0, acc0);
+                acc1 = mfma_split6(fa[ks], b1, acc1);
+            }
+        } else {
         load_frag(tn);
         __builtin_amdgcn_sched_barrier(0);
         const float* bp0 = &Ws[(t * 64 + i) * LDA + 4 * h];
@@ -848,6 +929,7 @@ __device__ __forceinline__ void wstat_body(
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, p4.w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, r4.w, acc1, 0, 0, 0);
             p4 = pn; r4 = rn;
+        }
         }
         if (last && tile * BMT + 32 * w + 31 < g.rows_total && out_off32) {
             // every row of the wave exists and the output fits 32-bit byte offsets (the common case): no per-row
@@ -981,12 +1063,12 @@ __device__ __forceinline__ void wstat_body(
     }
 }
 
-template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false>
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false, bool BF3 = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_gemm_wstat_kernel(
     ConvGeom g, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
     float* __restrict__ stats_part, int stats_rows, int tap0, int ntaps, BnBwd bnb = BnBwd{}) {
-    wstat_body<ACT, HAS_T, NW, PM, BNB, ACCUM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps,
+    wstat_body<ACT, HAS_T, NW, PM, BNB, ACCUM, BF3>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps,
                                         (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.x,
                                         (int)gridDim.x, bnb);
 }
@@ -999,25 +1081,28 @@ struct ConvGeomMulti {
     ConvGeom g[4];
     int begin[5];
 };
-template <int ACT, bool HAS_T, bool PM>
-__global__ __launch_bounds__(256, 2) void conv_gemm_wstat_multi_kernel(
+// BF3: the products run on the bf16 pipe (mfma_split6); 8 waves, one workgroup per CU (its four taps take 98 KB).
+template <int ACT, bool HAS_T, bool PM, bool BF3 = false>
+__global__ __launch_bounds__(BF3 ? 512 : 256, BF3 ? 1 : 2) void conv_gemm_wstat_multi_kernel(
     ConvGeomMulti p, const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, float* __restrict__ out,
     float* __restrict__ stats_part, int stats_rows) {
     const int b = blockIdx.x;
     const int ph = (b >= p.begin[1]) + (b >= p.begin[2]) + (b >= p.begin[3]);          // uniform
     const ConvGeom& g = p.g[ph];
-    wstat_body<ACT, HAS_T, 4, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows, 0, g.ntaps,
-                                  b - p.begin[ph], p.begin[ph + 1] - p.begin[ph], 0, b, (int)gridDim.x);
+    wstat_body<ACT, HAS_T, BF3 ? 8 : 4, PM, false, false, BF3>(g, A, Wt, bias, a_scale, a_shift, out, stats_part,
+                                                               stats_rows, 0, g.ntaps, b - p.begin[ph],
+                                                               p.begin[ph + 1] - p.begin[ph], 0, b, (int)gridDim.x);
 }
 
-template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false>
+template <int ACT, bool HAS_T, int NW, bool PM, bool BNB = false, bool ACCUM = false, bool BF3 = false>
 static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, const float* bias, const float* a_scale,
                         const float* a_shift, float* out, float* stats_part, int stats_rows, int n_col_blocks,
                         int tap0, int ntaps, hipStream_t st, BnBwd bnb = BnBwd{}) {
-    const size_t lds = (size_t)ntaps * 64 * LDA * sizeof(float) + 2 * NW * 32 * sizeof(int) + NW * 128 * sizeof(float);
+    const size_t lds = (BF3 ? (size_t)ntaps * BF3_TAP_BYTES : (size_t)ntaps * 64 * LDA * sizeof(float)) +
+                       2 * NW * 32 * sizeof(int) + NW * 128 * sizeof(float);
     static const bool opted = [] {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM>,
+        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM, BF3>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         return true;
@@ -1025,14 +1110,14 @@ static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, cons
     (void)opted;
     const int ntiles = (g.rows_total + 32 * NW - 1) / (32 * NW);
     // resident workgroups: two (NW = 4) or one (NW = 8) per CU
-    static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM>, 64 * NW,
+    static const int cap = resident_blocks((const void*)conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM, BF3>, 64 * NW,
                                            (NW == 4 ? 2 : 1) * compute_units());
     // (nn.Linear launches: the column blocks share the resident workgroups)
     int most = (NW == 4 ? 2 : 1) * compute_units() / (n_col_blocks > 0 ? n_col_blocks : 1);
     if (most < 1) most = 1;
     const int cap_use = cap < most ? cap : most;
     const dim3 grid(ntiles < cap_use ? ntiles : cap_use, n_col_blocks);
-    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
+    hipLaunchKernelGGL((conv_gemm_wstat_kernel<ACT, HAS_T, NW, PM, BNB, ACCUM, BF3>), grid, dim3(64 * NW), lds, st, g, A, Wt, bias,
                        a_scale, a_shift, out, stats_part, stats_rows, tap0, ntaps, bnb);
     return check_launch("conv_gemm_wstat_kernel");
 }
@@ -1595,6 +1680,13 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
     return g;
 }
 
+// rows from which a pixel-major weight-stationary launch runs its products on the bf16 pipe (BF3): from about three
+// 256-row tiles per CU on, as for the 8-wave fp32 kernel
+#ifndef CMVAE_BF3_MIN_ROWS
+#define CMVAE_BF3_MIN_ROWS (3 * 256 * 256)     // (a comparison build sets it out of reach: tools/ab_bench.sh)
+#endif
+static int bf3_min_rows() { return CMVAE_BF3_MIN_ROWS; }
+
 static int gemm_grid(int rows_total, int nblk_cols) {
     const int ntiles = (rows_total + BM - 1) / BM;
     int gx = 3 * compute_units() / (nblk_cols > 0 ? nblk_cols : 1);      // launch bounds: three workgroups per CU
@@ -1624,6 +1716,12 @@ extern "C" int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, co
     ConvGeomMulti p{};
     long work[4] = {0, 0, 0, 0}, total_work = 0, total_tiles = 0;
     int max_taps = 0;
+    // large pixel-major launches (the decoder's layers 2 and 3): products on the bf16 pipe, 256-row tiles, one
+    // workgroup of 8 waves per CU
+    long all_rows = 0;
+    for (int k = 0; k < ngeom; ++k) all_rows += geoms[k].rows_total;
+    const bool bf3 = to_geom(&geoms[0]).pm_nimg > 0 && all_rows >= (long)bf3_min_rows();
+    const int tile_rows = bf3 ? 256 : 128;
     for (int k = 0; k < ngeom; ++k) {
         p.g[k] = to_geom(&geoms[k]);
         const ConvGeom& g = p.g[k];
@@ -1632,7 +1730,7 @@ extern "C" int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, co
                       WSTAT_TAPS4);
         CMVAE_REQUIRE(g.rows_total > 0 && g.o_pitch >= 64, "cmvae_conv_gemm_multi: geometry %d is empty", k);
         CMVAE_REQUIRE((g.pm_nimg > 0) == (p.g[0].pm_nimg > 0), "cmvae_conv_gemm_multi: mixed row orders");
-        const long tiles = (g.rows_total + 127) / 128;
+        const long tiles = (g.rows_total + tile_rows - 1) / tile_rows;
         work[k] = tiles * g.ntaps;
         total_work += work[k];
         total_tiles += tiles;
@@ -1640,13 +1738,13 @@ extern "C" int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, co
     }
     for (int k = ngeom; k < 4; ++k) p.g[k] = p.g[0];
     // workgroups per geometry in proportion to its tap work, at least one, at most its tiles
-    int cap = 2 * compute_units();
+    int cap = (bf3 ? 1 : 2) * compute_units();
     if (total_tiles < cap) cap = (int)total_tiles;
     if (cap < ngeom) cap = ngeom;
     int nb[4] = {0, 0, 0, 0}, used = 0;
     for (int k = 0; k < ngeom; ++k) {
         long n = (long)cap * work[k] / total_work;
-        const long tiles = (p.g[k].rows_total + 127) / 128;
+        const long tiles = (p.g[k].rows_total + tile_rows - 1) / tile_rows;
         if (n < 1) n = 1;
         if (n > tiles) n = tiles;
         nb[k] = (int)n;
@@ -1663,7 +1761,7 @@ extern "C" int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, co
             for (int pass = 0; freed >= 8 && pass < 64; ++pass) {
                 int best = -1;
                 for (int k = 0; k < ngeom; ++k) {
-                    const long tiles = (p.g[k].rows_total + 127) / 128;
+                    const long tiles = (p.g[k].rows_total + tile_rows - 1) / tile_rows;
                     if (nb[k] + 8 <= tiles && (best < 0 || work[k] * nb[best] > work[best] * nb[k])) best = k;
                 }
                 if (best < 0) break;
@@ -1677,9 +1775,28 @@ extern "C" int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, co
     for (int k = 0; k < 4; ++k) p.begin[k + 1] = p.begin[k] + nb[k];
     // (begin[k] of an unused geometry is the grid size: never reached)
     const int stats_rows = 2 * compute_units();
-    const size_t lds = (size_t)max_taps * 64 * LDA * sizeof(float) + 2 * 4 * 32 * sizeof(int) + 4 * 128 * sizeof(float);
+    const int nw = bf3 ? 8 : 4;
+    const size_t lds = (bf3 ? (size_t)max_taps * BF3_TAP_BYTES : (size_t)max_taps * 64 * LDA * sizeof(float)) +
+                       2 * nw * 32 * sizeof(int) + nw * 128 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const bool pm = p.g[0].pm_nimg > 0;
+#define CMVAE_MULTI_BF3(HAS_T)                                                                                         \
+    do {                                                                                                               \
+        static const bool opted = [] {                                                                                 \
+            (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_multi_kernel<0, HAS_T, true, true>,                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+            (void)hipGetLastError();                                                                                   \
+            return true;                                                                                               \
+        }();                                                                                                           \
+        (void)opted;                                                                                                   \
+        hipLaunchKernelGGL((conv_gemm_wstat_multi_kernel<0, HAS_T, true, true>), dim3(used), dim3(512), lds, st, p, A, \
+                           Wt, bias, a_scale, a_shift, out, stats_part, stats_rows);                                   \
+    } while (0)
+    if (bf3) {
+        if (a_scale) CMVAE_MULTI_BF3(true); else CMVAE_MULTI_BF3(false);
+        return check_launch("conv_gemm_wstat_multi_kernel (bf16 pipe)");
+    }
+#undef CMVAE_MULTI_BF3
 #define CMVAE_MULTI(HAS_T, PM)                                                                                         \
     do {                                                                                                               \
         static const bool opted = [] {                                                                                 \
