@@ -18,6 +18,7 @@
 // The weight-gradient kernels contract over r instead (conv_wgrad_stream_kernel: fragments straight from global
 // memory on v_mfma_f32_16x16x4_f32; conv_wgrad_kernel: LDS-staged, any shape).
 #include "common.h"
+#include <utility>
 #ifndef CMVAE_ABLATE
 #define CMVAE_ABLATE 0
 #endif
@@ -109,8 +110,9 @@ struct RowDecoder {
 
 // Taps tap0 .. tap0+ntaps-1 that are inside the image for at least one row of tile [row0, row0 + rows), as a bit mask
 // (wave-uniform scalar code).  Image-major order, a tile that spans two grid positions, or a tile with no valid tap
-// at all: every tap (rows are masked individually either way; the mask only removes work that is zero for the whole
-// tile).
+// (image-major, or a tile that spans two grid positions): every tap (rows are masked individually either way; the mask
+// only removes work that is zero for the whole tile).  A tile with no valid tap at all — a tap group of an accumulating
+// data gradient at a border position — takes the first tap, fully masked: its epilogue still runs.
 struct TileInfo { unsigned mask; };
 template <bool PM>
 __device__ __forceinline__ TileInfo tile_info(const ConvGeom& g, int row0, int rows, int tap0, int ntaps) {
@@ -130,7 +132,7 @@ __device__ __forceinline__ TileInfo tile_info(const ConvGeom& g, int row0, int r
         const bool in = ((unsigned)(ys + g.dy[tap0 + t]) < (unsigned)g.Hi) & ((unsigned)(xs + g.dx[tap0 + t]) < (unsigned)g.Wi);
         m |= in ? (1u << t) : 0u;
     }
-    ti.mask = __builtin_amdgcn_readfirstlane(m ? m : full);
+    ti.mask = __builtin_amdgcn_readfirstlane(m ? m : 1u);
     return ti;
 }
 // The tap tables of a launch held in registers: lane t (mod 32) of a wave keeps tap t's offsets, a wave-uniform tap
@@ -163,7 +165,7 @@ struct TapTable {
         const bool in = (lane < 32) & (tl >= tap0) & (tl < tap0 + ntaps) &
                         ((unsigned)(y * g.sy + dy) < (unsigned)g.Hi) & ((unsigned)(x * g.sx + dx) < (unsigned)g.Wi);
         const unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(in) >> tap0;
-        ti.mask = m ? m : full;
+        ti.mask = m ? m : 1u;
         return ti;
     }
 };
@@ -287,18 +289,32 @@ __device__ __forceinline__ float4 scaled4(const float4& v, float f) { return mak
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 struct Split3 { unsigned p1, p2, p3; };                  // two values per register: low half = the first one's piece
-__device__ __forceinline__ Split3 split_pair(float x, float y) {
+// Selectors of v_dot2c_f32_bf16 (a.lo b.lo + a.hi b.hi + c) that subtract one half of a packed pair: (-1, 0) and
+// (0, -1).  Made once per kernel and kept in registers: as an inline constant the assembler's -1.0 is not the
+// packed-bf16 pattern.
+struct SplitSel { bf16x2 m10, m01; };
+__device__ __forceinline__ SplitSel make_split_sel() {
+    unsigned u10 = 0x0000bf80u, u01 = 0xbf800000u;
+    asm volatile("" : "+v"(u10), "+v"(u01));
+    return SplitSel{__builtin_bit_cast(bf16x2, u10), __builtin_bit_cast(bf16x2, u01)};
+}
+__device__ __forceinline__ Split3 split_pair(float x, float y, const SplitSel& q) {
+    // the residual x - bf16(x) in ONE instruction per value (exact: the products are exact and the difference is
+    // representable)
     Split3 s;
-    s.p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{x, y}, bf16x2));
-    const floatx2 r = floatx2{x, y} - floatx2{__uint_as_float(s.p1 << 16), __uint_as_float(s.p1 & 0xffff0000u)};
-    s.p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-    const floatx2 r2 = r - floatx2{__uint_as_float(s.p2 << 16), __uint_as_float(s.p2 & 0xffff0000u)};
-    s.p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+    const bf16x2 h1 = __builtin_convertvector(floatx2{x, y}, bf16x2);
+    const float rx = __builtin_amdgcn_fdot2_f32_bf16(h1, q.m10, x, false), ry = __builtin_amdgcn_fdot2_f32_bf16(h1, q.m01, y, false);
+    const bf16x2 h2 = __builtin_convertvector(floatx2{rx, ry}, bf16x2);
+    const float sx = __builtin_amdgcn_fdot2_f32_bf16(h2, q.m10, rx, false), sy = __builtin_amdgcn_fdot2_f32_bf16(h2, q.m01, ry, false);
+    const bf16x2 h3 = __builtin_convertvector(floatx2{sx, sy}, bf16x2);
+    s.p1 = __builtin_bit_cast(unsigned, h1);
+    s.p2 = __builtin_bit_cast(unsigned, h2);
+    s.p3 = __builtin_bit_cast(unsigned, h3);
     return s;
 }
 struct Frag3 { uint4 p[3]; };                            // 8 values: three planes of 8 bf16
-__device__ __forceinline__ Frag3 split8(const float4& u, const float4& v) {
-    const Split3 a = split_pair(u.x, u.y), b = split_pair(u.z, u.w), c = split_pair(v.x, v.y), d = split_pair(v.z, v.w);
+__device__ __forceinline__ Frag3 split8(const float4& u, const float4& v, const SplitSel& q) {
+    const Split3 a = split_pair(u.x, u.y, q), b = split_pair(u.z, u.w, q), c = split_pair(v.x, v.y, q), d = split_pair(v.z, v.w, q);
     Frag3 f;
     f.p[0] = make_uint4(a.p1, b.p1, c.p1, d.p1);
     f.p[1] = make_uint4(a.p2, b.p2, c.p2, d.p2);
@@ -321,6 +337,7 @@ __device__ __forceinline__ floatx16 mfma_split6(const Frag3& a, const Frag3& b, 
 // q ^ ((co >> 1) & 7), which makes the ds_read_b128 of 16 consecutive rows conflict-free without padding (six taps
 // fit 160 KB: 147 456 bytes).
 constexpr int BF3_TAP_BYTES = 3 * 64 * 128;
+constexpr int BF3_TAPS = 6;                              // taps whose planes fit LDS at once
 __device__ __forceinline__ int bf3_elem(int pl, int co, int chunk) {         // element (bf16) index within a tap
     return ((pl * 64 + co) * 8 + (chunk ^ ((co >> 1) & 7))) * 8;
 }
@@ -746,6 +763,7 @@ __device__ __forceinline__ void wstat_body(
     const int i = lane & 31, h = lane >> 5;
     const int q = tid & 15, rb = tid >> 4;
     const int nb = nb_in;
+    const SplitSel ssel = make_split_sel();
     {
         const float* Wn = Wt + nb * g.w_nblk_stride + 4 * q;
         for (int t = 0; t < ntaps; ++t)
@@ -755,7 +773,7 @@ __device__ __forceinline__ void wstat_body(
                 if (BF3) {
                     // channels 4q .. 4q+3 = float4 kk = q / 2 of lane half q & 1: chunk 2 (kk / 2) + (q & 1), elements
                     // 4 (kk & 1) .. + 3 of it
-                    const Split3 s0 = split_pair(wv.x, wv.y), s1 = split_pair(wv.z, wv.w);
+                    const Split3 s0 = split_pair(wv.x, wv.y, ssel), s1 = split_pair(wv.z, wv.w, ssel);
                     const int kk = q >> 1, chunk = 2 * (kk >> 1) + (q & 1), sub = 4 * (kk & 1);
                     __bf16* wt = Wp + (size_t)t * (BF3_TAP_BYTES / 2) + sub;
                     *reinterpret_cast<uint2*>(wt + bf3_elem(0, row, chunk)) = make_uint2(s0.p1, s1.p1);
@@ -889,7 +907,7 @@ __device__ __forceinline__ void wstat_body(
         if (BF3) {
             Frag3 fa[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fa[ks] = split8(a[2 * ks], a[2 * ks + 1]);
+            for (int ks = 0; ks < 4; ++ks) fa[ks] = split8(a[2 * ks], a[2 * ks + 1], ssel);
             load_frag(tn);
             __builtin_amdgcn_sched_barrier(0);
             const __bf16* wt = Wp + (size_t)t * (BF3_TAP_BYTES / 2);
@@ -1499,6 +1517,264 @@ __device__ __forceinline__ void wgrad_stream_body(const ConvGeom& g, int tap0, i
     }
 }
 
+// ---------------------------------------------------------------------------- weight gradient on the bf16 pipe
+// The streaming kernel above with its products on the bf16 matrix pipe (mfma_split6's scheme, here with
+// v_mfma_f32_16x16x32_bf16: k = 8 (lane >> 4) + e, e = 0..7).  A chunk is 32 images at one grid position; lane (i, kg)
+// loads channels 4i .. 4i+3 of images 8 kg .. 8 kg + 7 (eight 16-byte loads per operand, each instruction 4 x 256
+// contiguous bytes), so component ja of its eight registers IS the A fragment of sub-lattice ja and component jb of the
+// gradient's the B fragment of jb — split into three bf16 planes in registers, no transposition anywhere.  The
+// accumulator layout, the combination of the row streams and the partials are those of wgrad_stream_body.
+// One workgroup per CU (512 registers per lane: 128 accumulators, both operands' raw rows of the next chunk in
+// flight, the gradient's twelve fragment registers x 4): the split of one fragment is interleaved with the MFMAs of the
+// previous one.
+__device__ __forceinline__ floatx4 mfma16_split6(const Frag3& a, const Frag3& b, floatx4 c) {       // small terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[2]), as_bf(b.p[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[0]), as_bf(b.p[2]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[1]), as_bf(b.p[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[1]), as_bf(b.p[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[0]), as_bf(b.p[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[0]), as_bf(b.p[0]), c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+// component j of eight rows -> the three planes of one 8-value fragment
+__device__ __forceinline__ Frag3 split_rows(const float4 (&r)[8], int j, const SplitSel& q) {
+    const Split3 a = split_pair(comp4(r[0], j), comp4(r[1], j), q), b = split_pair(comp4(r[2], j), comp4(r[3], j), q),
+                 c = split_pair(comp4(r[4], j), comp4(r[5], j), q), d = split_pair(comp4(r[6], j), comp4(r[7], j), q);
+    Frag3 f;
+    f.p[0] = make_uint4(a.p1, b.p1, c.p1, d.p1);
+    f.p[1] = make_uint4(a.p2, b.p2, c.p2, d.p2);
+    f.p[2] = make_uint4(a.p3, b.p3, c.p3, d.p3);
+    return f;
+}
+
+template <bool HAS_T>
+__device__ __forceinline__ void wgrad_bf3_body(const ConvGeom& g, int tap0, int nt, int nimg,
+                                               const float* __restrict__ A, const float* __restrict__ a_scale,
+                                               const float* __restrict__ a_shift, const float* __restrict__ G,
+                                               int g_pitch, int g_col, float* __restrict__ part,
+                                               float* __restrict__ db_part, int bid, int nblk, int nt_stride,
+                                               float* comb) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kq = lane >> 4;
+    const SplitSel ssel = make_split_sel();
+    const bool split = nt > 2;                                   // two tap pairs x two row streams, else four row streams
+    const int tp = split ? (w & 1) : 0;
+    const int p = split ? (w >> 1) : w;
+    const int P = split ? 2 : 4;
+    const int npix = g.Hg * g.Wg;
+    const int nchunks = (nimg / 32) * npix;
+    const int nstreams = nblk * P, sid = bid * P + p;
+    const int c_begin = (int)((long)nchunks * sid / nstreams), c_end = (int)((long)nchunks * (sid + 1) / nstreams);
+    const int t_u[2] = {split ? tp : 0, split ? 3 - tp : 1};     // (the pairing of wgrad_stream_body)
+    const int img_a = g.Hi * g.Wi * g.a_pitch, img_g = g.Ho * g.Wo * g_pitch;
+
+    float4 sc[2], sh[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        sc[u] = make_float4(1.f, 1.f, 1.f, 1.f); sh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (HAS_T && t_u[u] < nt) {
+            sc[u] = scaled4(*reinterpret_cast<const float4*>(a_scale + g.a_col[tap0 + t_u[u]] + 4 * i), FOLD_DOWN);
+            sh[u] = scaled4(*reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t_u[u]] + 4 * i), FOLD_DOWN);
+        }
+    }
+    // the lane's part of every address, in bytes and unsigned: scalar base + one 32-bit VGPR offset per load
+    const unsigned lane_a = (unsigned)(8 * kq * img_a + 4 * i) * 4u, lane_g = (unsigned)(8 * kq * img_g + 4 * i) * 4u;
+    auto describe = [&](int ib, int y, int x, bool live) {
+        ChunkDesc d;
+        const int img = ib * 32;
+        const int ys = y * g.sy, xs = x * g.sx;
+        d.valid = live ? 4u : 0u;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bool in = false;
+            int off = 0;
+            if (t_u[u] < nt) {
+                const int t = tap0 + t_u[u];
+                const int dy = g.dy[t], dx = g.dx[t];
+                in = live & ((unsigned)(ys + dy) < (unsigned)g.Hi) & ((unsigned)(xs + dx) < (unsigned)g.Wi);
+                off = ((img * g.Hi + ys + dy) * g.Wi + xs + dx) * g.a_pitch + g.a_col[t];
+            }
+            d.a[u] = in ? off : 0;
+            d.sa[u] = in ? img_a : 0;                            // step between consecutive images
+            d.valid |= in ? (1u << u) : 0u;
+        }
+        const int op = (img * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
+        d.go = live ? op * g_pitch + g_col : 0;
+        d.sg = live ? img_g : 0;
+#if CMVAE_ABLATE == 7      // every operand load hits the same few rows: the compute-side ceiling of this loop
+        d.a[0] = d.a[1] = d.go = 0; d.sa[0] = d.sa[1] = d.sg = 0;
+#elif CMVAE_ABLATE == 71   // ... only the operand's loads do
+        d.a[0] = d.a[1] = 0; d.sa[0] = d.sa[1] = 0;
+#elif CMVAE_ABLATE == 72   // ... only the gradient's
+        d.go = 0; d.sg = 0;
+#endif
+        return d;
+    };
+
+    floatx4 acc[2][16];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[u][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float db_on = (db_part != nullptr && tp == 0) ? 1.f : 0.f;
+
+    float4 rx[2][8], rg[8];
+    auto issue_x = [&](int u, const ChunkDesc& d) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            rx[u][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A + (d.a[u] + j * d.sa[u])) + lane_a);
+    };
+    auto issue_g = [&](const ChunkDesc& d) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            rg[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(G + (d.go + j * d.sg)) + lane_g);
+    };
+
+    int c = c_begin;
+    int ib = c / npix;
+    int y, x;
+    { const int pix = c - ib * npix; y = pix / g.Wg; x = pix - y * g.Wg; }
+    ChunkDesc cur = describe(ib, y, x, c < c_end);
+    issue_x(0, cur);
+    issue_x(1, cur);
+    issue_g(cur);
+    for (; c < c_end; ++c) {
+        if (++x == g.Wg) { x = 0; if (++y == g.Hg) { y = 0; ++ib; } }
+        const ChunkDesc nxt = describe(ib, y, x, c + 1 < c_end);
+        // Both taps' operand rows folded, and the next chunk's requested into the freed registers at once: the operand
+        // rows are the ones that miss (re-read rows at shifted positions; the gradient streams), measured +350 us of
+        // stall at layer 3 against none for the gradient's.  Then the bias-gradient sum and the four B fragments, and
+        // the next chunk's gradient rows.  The requests are pinned: left to itself the compiler sinks them to the end
+        // of the iteration and the next one starts with their full latency.
+        float4 a[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // a tap outside the image at this position (uniform; 7 % of the tap x position pairs of a 14 x 14 grid)
+            // multiplies zeros: a branch around the MFMAs costs a copy of the 64 accumulators on either path
+            const float von = ((cur.valid >> u) & 1u) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 f = fold_a_scaled<HAS_T>(rx[u][j], sc[u], sh[u]);
+                const floatx2 lo = floatx2{f.x, f.y} * floatx2{von, von}, hi = floatx2{f.z, f.w} * floatx2{von, von};
+                a[u][j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(0, nxt);
+        issue_x(1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            floatx2 lo = {dbs.x, dbs.y}, hi = {dbs.z, dbs.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lo = __builtin_elementwise_fma(floatx2{rg[j].x, rg[j].y}, floatx2{db_on, db_on}, lo);
+                hi = __builtin_elementwise_fma(floatx2{rg[j].z, rg[j].w}, floatx2{db_on, db_on}, hi);
+            }
+            dbs = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+        Frag3 gB[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) gB[jb] = split_rows(rg, jb, ssel);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_g(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        Frag3 xa = split_rows(a[0], 0, ssel);
+        // eight stages (tap u, sub-lattice ja): 24 MFMAs each, the next stage's A fragment split in their gaps
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int u = st >> 2, ja = st & 3;
+            Frag3 xn = xa;
+            if (st < 7) xn = split_rows(a[(st + 1) >> 2], (st + 1) & 3, ssel);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[u][ja * 4 + jb] = mfma16_split6(xa, gB[jb], acc[u][ja * 4 + jb]);
+            if (st < 7) {
+#pragma unroll
+                for (int m = 0; m < 14; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            xa = xn;
+        }
+        cur = nxt;
+    }
+
+    if (HAS_T) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[u][k] *= FOLD_UP;          // exact: the operand was folded times 2^-60
+    }
+    // add the row streams of a tap pair (wave p == 0 keeps the sum): lane-major LDS image of the 128 accumulators
+    float* cb = comb + tp * 8192 + lane;
+    for (int k = 1; k < P; ++k) {
+        if (p == k) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 64; ++r) cb[(u * 64 + r) * 64] = acc[u][r >> 2][r & 3];
+        }
+        __syncthreads();
+        if (p == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 64; ++r) acc[u][r >> 2][r & 3] += cb[(u * 64 + r) * 64];
+        }
+        __syncthreads();
+    }
+    if (db_part) {
+        dbs.x += __shfl_xor(dbs.x, 16); dbs.y += __shfl_xor(dbs.y, 16); dbs.z += __shfl_xor(dbs.z, 16); dbs.w += __shfl_xor(dbs.w, 16);
+        dbs.x += __shfl_xor(dbs.x, 32); dbs.y += __shfl_xor(dbs.y, 32); dbs.z += __shfl_xor(dbs.z, 32); dbs.w += __shfl_xor(dbs.w, 32);
+        if (tp == 0 && kq == 0) *reinterpret_cast<float4*>(&comb[p * 64 + 4 * i]) = dbs;
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+            for (int k = 0; k < P; ++k) sum += comb[k * 64 + tid];
+            db_part[(long)bid * 64 + tid] = sum;
+        }
+    }
+    if (p == 0) {
+        float* pb = part + (long)bid * nt_stride * 4096;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (t_u[u] >= nt) continue;
+#pragma unroll
+            for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = 16 * kq + 4 * r + ja;
+                    *reinterpret_cast<float4*>(&pb[t_u[u] * 4096 + ci * 64 + 4 * i]) =
+                        make_float4(acc[u][ja * 4 + 0][r], acc[u][ja * 4 + 1][r], acc[u][ja * 4 + 2][r], acc[u][ja * 4 + 3][r]);
+                }
+        }
+    }
+}
+
+// the sub-pixel phases of a transposed convolution in one launch (see conv_wgrad_stream_multi_kernel), bf16 pipe
+template <bool HAS_T>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_bf3_multi_kernel(ConvGeomMulti p, int nimg, int db_blocks,
+                                                                      const float* __restrict__ A,
+                                                                      const float* __restrict__ a_scale,
+                                                                      const float* __restrict__ a_shift,
+                                                                      const float* __restrict__ G, int g_pitch,
+                                                                      float* __restrict__ part,
+                                                                      float* __restrict__ db_part) {
+    __shared__ __align__(16) float comb[2 * 128 * 64];
+    const int b = blockIdx.x;
+    const int ph = (b >= p.begin[1]) + (b >= p.begin[2]) + (b >= p.begin[3]);          // uniform
+    const ConvGeom& g = p.g[ph];
+    const int b0 = p.begin[ph];
+    wgrad_bf3_body<HAS_T>(g, 0, g.ntaps, nimg, A, a_scale, a_shift, G, g_pitch, 0, part + (long)b0 * 4 * 4096,
+                          (db_part && b < db_blocks) ? db_part + (long)b0 * 64 : nullptr, b - b0,
+                          p.begin[ph + 1] - b0, 4, comb);
+}
+
 template <bool HAS_T>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_stream_kernel(ConvGeom g, int tap0, int nt, int nimg,
                                                                    const float* __restrict__ A,
@@ -1869,24 +2145,6 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
     return check_launch("conv_gemm_kernel");
 }
 
-// rows from which a 16-tap data gradient runs as two accumulating weight-stationary launches (below it the direct
-// kernel is faster: layer 1's 153 600 rows take 133 us there against 79 + 84 us split)
-static int split_dgrad_min_rows() { return 3 * 256 * 256; }
-// every grid position keeps at least one in-image tap in taps [0, n/2) and in [n/2, n)
-static bool halves_nonempty(const ConvGeom& g) {
-    const int h0 = g.ntaps / 2;
-    for (int y = 0; y < g.Hg; ++y)
-        for (int x = 0; x < g.Wg; ++x) {
-            bool a = false, b = false;
-            for (int t = 0; t < g.ntaps; ++t) {
-                const bool in = (unsigned)(y * g.sy + g.dy[t]) < (unsigned)g.Hi && (unsigned)(x * g.sx + g.dx[t]) < (unsigned)g.Wi;
-                if (in) (t < h0 ? a : b) = true;
-            }
-            if (!a || !b) return false;
-        }
-    return true;
-}
-
 extern "C" int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A, const float* Wt, float* out,
                                      const float* x, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, float* sums_part, void* stream) {
@@ -1904,16 +2162,22 @@ extern "C" int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A
     hipStream_t st = (hipStream_t)stream;
     const BnBwd bnb{x, scale, shift, mean, invstd};
     const float* none = nullptr;
-    if (g.pm_nimg > 0 && g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256)
+    // large pixel-major launches: products on the bf16 pipe (mfma_split6), at most BF3_TAPS taps' weight planes in LDS
+    // per pass, later passes adding to the output; the last one carries the BatchNorm-backward sums
+    // (7 .. 9 taps fit LDS at once as fp32 and would take two passes here: layer 2's 9-tap data gradient ran 347 us in
+    // 4 + 5 taps on the bf16 pipe against 308 in one fp32 launch)
+    if (g.pm_nimg > 0 && g.ntaps > BF3_TAPS && g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256)
         return launch_wstat<0, false, 8, true, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, 0, g.ntaps, st, bnb);
-    // 10 .. 16 taps (the 4x4 transposed convs' data gradients): two weight-stationary launches of half the taps each,
-    // the second adding to the first one's output — the read-modify-write of the output (0.5 GB at layer 3) costs less
-    // than the direct kernel's two barriers and weight staging per tap.  Every tile must keep a tap in both halves.
-    if (g.pm_nimg > 0 && g.ntaps > WSTAT_TAPS8 && g.ntaps <= 16 && g.rows_total >= split_dgrad_min_rows() &&
-        halves_nonempty(g)) {
-        const int h0 = g.ntaps / 2;
-        if (int e = launch_wstat<0, false, 8, true, false, false>(g, A, Wt, none, none, none, out, nullptr, 0, 1, 0, h0, st)) return e;
-        return launch_wstat<0, false, 8, true, true, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, h0, g.ntaps - h0, st, bnb);
+    if (g.pm_nimg > 0 && g.rows_total >= bf3_min_rows() && g.ntaps <= 3 * BF3_TAPS) {
+        const int ngrp = (g.ntaps + BF3_TAPS - 1) / BF3_TAPS;
+        if (ngrp == 1)
+            return launch_wstat<0, false, 8, true, true, false, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, 0, g.ntaps, st, bnb);
+        // (a tile with no in-image tap in a pass adds zero from one masked tap: tile_info)
+        const int b1 = g.ntaps / ngrp, b2 = ngrp == 3 ? 2 * g.ntaps / 3 : b1;
+        if (int e = launch_wstat<0, false, 8, true, false, false, true>(g, A, Wt, none, none, none, out, nullptr, 0, 1, 0, b1, st)) return e;
+        if (ngrp == 3)
+            if (int e = launch_wstat<0, false, 8, true, false, true, true>(g, A, Wt, none, none, none, out, nullptr, 0, 1, b1, b2 - b1, st)) return e;
+        return launch_wstat<0, false, 8, true, true, true, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, b2, g.ntaps - b2, st, bnb);
     }
     const dim3 grid(gx, 1);
     if (g.pm_nimg > 0)
@@ -2079,12 +2343,16 @@ extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, c
     }
     // workgroups per geometry in proportion to the time of one of its row streams: chunks / streams per workgroup,
     // a lone tap costing about 0.6 of a pair
-    const int max_blocks = wgrad_grid(1 << 30);
+    // large launches whose image count is a multiple of 32: products on the bf16 pipe, one workgroup per CU
+    long all_rows = 0;
+    for (int k = 0; k < ngeom; ++k) all_rows += p.g[k].rows_total;
+    const bool bf3 = nimg % 32 == 0 && all_rows >= (long)bf3_min_rows();
+    const int max_blocks = bf3 ? compute_units() : wgrad_grid(1 << 30);
     double wsum = 0., wk[4] = {0., 0., 0., 0.};
     long chunks[4] = {0, 0, 0, 0};
     for (int k = 0; k < ngeom; ++k) {
         const ConvGeom& g = p.g[k];
-        chunks[k] = (long)(nimg / 16) * g.Hg * g.Wg;
+        chunks[k] = (long)(nimg / (bf3 ? 32 : 16)) * g.Hg * g.Wg;
         wk[k] = (double)chunks[k] / (g.ntaps > 2 ? 2 : 4) * (g.ntaps == 1 ? 0.6 : 1.0);
         wsum += wk[k];
     }
@@ -2104,8 +2372,15 @@ extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, c
     }
     CMVAE_REQUIRE(used <= max_blocks, "cmvae_conv_wgrad_multi: %d workgroups exceed the workspace", used);
     float* part = (float*)workspace;
-    float* db_part = (float*)((char*)workspace + align_up((size_t)max_blocks * 4 * 4096 * sizeof(float)));
+    float* db_part = (float*)((char*)workspace + align_up((size_t)wgrad_grid(1 << 30) * 4 * 4096 * sizeof(float)));
     float* dbp = db ? db_part : nullptr;
+    if (bf3) {
+        if (a_scale) hipLaunchKernelGGL(conv_wgrad_bf3_multi_kernel<true>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
+        else hipLaunchKernelGGL(conv_wgrad_bf3_multi_kernel<false>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
+        if (int e = check_launch("conv_wgrad_bf3_multi_kernel")) return e;
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(4 * 64 + 1, ngeom), dim3(1024), 0, st, part, o, dW, dbp, db, used, 0);
+        return check_launch("wgrad_reduce_multi_kernel");
+    }
     if (a_scale) hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<true>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
     else hipLaunchKernelGGL(conv_wgrad_stream_multi_kernel<false>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
     if (int e = check_launch("conv_wgrad_stream_multi_kernel")) return e;

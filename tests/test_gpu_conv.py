@@ -173,7 +173,7 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
 
 def test_dgrad_bn_sums_epilogue_weight_stationary_kernel(device):
     """Layer-2 shape of the training step (9-tap data gradient, >= 196608 rows: the eight-wave weight-stationary
-    kernel): gradient bit-equal to the plain launch, sums equal to the separate reduction pass."""
+    kernel): gradient equal to the plain launch, sums equal to the separate reduction pass."""
     from cmvae_amd import conv, decoder
     n, Hi, k = 12304, 4, 3
     Ho = conv.convT_out(Hi, k)
@@ -188,8 +188,10 @@ def test_dgrad_bn_sums_epilogue_weight_stationary_kernel(device):
     conv.conv_gemm(gd, gy, wtd, want)
     got = torch.full_like(want, float('nan'))
     part = conv.conv_gemm_bnbwd(gd, gy, wtd, got, x, fold)
-    assert torch.equal(got, want)
-    s_want = decoder.bn_relu_bwd_sums(want, x, fold, masked=False)
+    # (the launch with the sums runs its products on the bf16 pipe in two accumulating passes of 5 + 4 taps: the same
+    # sums to fp32 rounding)
+    assert rel_err(got, want) < 1e-6 and float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
+    s_want = decoder.bn_relu_bwd_sums(got, x, fold, masked=False)
     s_got = decoder.colsum(part)
     assert rel_err(s_got[:64], s_want[:64]) < 1e-5 and rel_err(s_got[64:], s_want[64:]) < 1e-5
 
@@ -222,9 +224,10 @@ def test_bn_finalize_from_partials_equals_two_step_path(device, nblk):
 
 
 def test_dgrad_bn_sums_sixteen_taps_in_two_accumulating_launches(device):
-    """Layer-3 shape of the training step (16-tap data gradient over >= 196608 rows): two weight-stationary launches
-    of eight taps, the second adding to the first one's output.  The two half sums are added in another order than
-    the single accumulator chain of the direct kernel: equal to rounding; the sums equal the separate reduction."""
+    """Layer-3 shape of the training step (16-tap data gradient over >= 196608 rows): three weight-stationary launches
+    of 5 + 5 + 6 taps on the bf16 pipe, the later ones adding to the output.  The partial sums are added in another
+    order than the single accumulator chain of the direct kernel: equal to rounding; the sums equal the separate
+    reduction."""
     from cmvae_amd import conv, decoder
     n, Hi, k = 4112, 7, 4
     Ho = conv.convT_out(Hi, k)

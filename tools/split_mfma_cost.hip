@@ -34,22 +34,33 @@ constexpr int LDB = 72;        // bf16 weight rows in LDS (bf16 elements: 144 by
 struct Split3 { unsigned p1, p2, p3; };       // two values per register: low half = first value's piece
 
 // round-to-nearest pieces: x = x1 + x2 + x3 exactly (each residual is exact in fp32)
-__device__ __forceinline__ Split3 split_pair(float x, float y) {
+// Selectors of v_dot2c_f32_bf16 (a.lo b.lo + a.hi b.hi + c) that subtract one half of a packed pair: (-1, 0) and
+// (0, -1).  Made once per kernel and kept in registers: as an inline constant the assembler's -1.0 is not the
+// packed-bf16 pattern.
+struct SplitSel { bf16x2 m10, m01; };
+__device__ __forceinline__ SplitSel make_split_sel() {
+    unsigned u10 = 0x0000bf80u, u01 = 0xbf800000u;
+    asm volatile("" : "+v"(u10), "+v"(u01));
+    return SplitSel{__builtin_bit_cast(bf16x2, u10), __builtin_bit_cast(bf16x2, u01)};
+}
+__device__ __forceinline__ Split3 split_pair(float x, float y, const SplitSel& q) {
+    // the residual x - bf16(x) in ONE instruction per value (exact: the products are exact and the difference is
+    // representable)
     Split3 s;
     const bf16x2 h1 = __builtin_convertvector(floatx2{x, y}, bf16x2);
+    const float rx = __builtin_amdgcn_fdot2_f32_bf16(h1, q.m10, x, false), ry = __builtin_amdgcn_fdot2_f32_bf16(h1, q.m01, y, false);
+    const bf16x2 h2 = __builtin_convertvector(floatx2{rx, ry}, bf16x2);
+    const float sx = __builtin_amdgcn_fdot2_f32_bf16(h2, q.m10, rx, false), sy = __builtin_amdgcn_fdot2_f32_bf16(h2, q.m01, ry, false);
+    const bf16x2 h3 = __builtin_convertvector(floatx2{sx, sy}, bf16x2);
     s.p1 = __builtin_bit_cast(unsigned, h1);
-    const floatx2 r = floatx2{x, y} - floatx2{__uint_as_float(s.p1 << 16), __uint_as_float(s.p1 & 0xffff0000u)};
-    const bf16x2 h2 = __builtin_convertvector(r, bf16x2);
     s.p2 = __builtin_bit_cast(unsigned, h2);
-    const floatx2 r2 = r - floatx2{__uint_as_float(s.p2 << 16), __uint_as_float(s.p2 & 0xffff0000u)};
-    const bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
     s.p3 = __builtin_bit_cast(unsigned, h3);
     return s;
 }
 
 struct Frag3 { uint4 p[3]; };
-__device__ __forceinline__ Frag3 split8(const float4& u, const float4& v) {
-    const Split3 a = split_pair(u.x, u.y), b = split_pair(u.z, u.w), c = split_pair(v.x, v.y), d = split_pair(v.z, v.w);
+__device__ __forceinline__ Frag3 split8(const float4& u, const float4& v, const SplitSel& q) {
+    const Split3 a = split_pair(u.x, u.y, q), b = split_pair(u.z, u.w, q), c = split_pair(v.x, v.y, q), d = split_pair(v.z, v.w, q);
     Frag3 f;
     f.p[0] = make_uint4(a.p1, b.p1, c.p1, d.p1);
     f.p[1] = make_uint4(a.p2, b.p2, c.p2, d.p2);
@@ -77,6 +88,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void k(const float* __restr
                                                              long long* cycles) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, h = lane >> 5;
+    const SplitSel ssel = make_split_sel();
     constexpr int RW = MODE == 2 ? 64 : 32;                         // rows per wave
     if (MODE == 0) {
         float* Ws = reinterpret_cast<float*>(smem);
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void k(const float* __restr
         __bf16* Wp = reinterpret_cast<__bf16*>(smem);
         for (int e = tid; e < 64 * 32; e += 256) {
             const int co = e >> 5, c = 2 * (e & 31);
-            const Split3 s = split_pair(W[co * 64 + c], W[co * 64 + c + 1]);
+            const Split3 s = split_pair(W[co * 64 + c], W[co * 64 + c + 1], ssel);
             const int kk = c >> 3, hh = (c >> 2) & 1, j = c & 3;
             const int pos = 16 * (kk >> 1) + 8 * hh + 4 * (kk & 1) + j;
             *reinterpret_cast<unsigned*>(&Wp[(0 * 64 + co) * LDB + pos]) = s.p1;
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void k(const float* __restr
     if (MODE == 3) {
         Frag3 fa[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fa[ks] = split8(ra[2 * ks], ra[2 * ks + 1]);
+        for (int ks = 0; ks < 4; ++ks) fa[ks] = split8(ra[2 * ks], ra[2 * ks + 1], ssel);
         load(1);
         const __bf16* Wp = reinterpret_cast<const __bf16*>(smem);
         for (int s = 0; s < steps; ++s) {
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void k(const float* __restr
                     b0.p[pl] = *reinterpret_cast<const uint4*>(&Wp[(pl * 64 + i) * LDB + 16 * ks + 8 * h]);
                     b1.p[pl] = *reinterpret_cast<const uint4*>(&Wp[(pl * 64 + 32 + i) * LDB + 16 * ks + 8 * h]);
                 }
-                fn[ks] = split8(ra[2 * ks], ra[2 * ks + 1]);                   // step s + 1
+                fn[ks] = split8(ra[2 * ks], ra[2 * ks + 1], ssel);                   // step s + 1
                 ra[2 * ks] = *reinterpret_cast<const float4*>(pn + 16 * ks);     // step s + 2
                 ra[2 * ks + 1] = *reinterpret_cast<const float4*>(pn + 16 * ks + 8);
                 acc[0] = mfma6(fa[ks], b0, acc[0]);
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void k(const float* __restr
 #pragma unroll
             for (int r = 0; r < NR; ++r)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) fa[r][ks] = split8(ra[8 * r + 2 * ks], ra[8 * r + 2 * ks + 1]);
+                for (int ks = 0; ks < 4; ++ks) fa[r][ks] = split8(ra[8 * r + 2 * ks], ra[8 * r + 2 * ks + 1], ssel);
             load(s + 1);
             __builtin_amdgcn_sched_barrier(0);
             const __bf16* Wp = reinterpret_cast<const __bf16*>(smem);
