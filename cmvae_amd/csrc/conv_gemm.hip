@@ -1756,8 +1756,227 @@ __device__ __forceinline__ void wgrad_bf3_body(const ConvGeom& g, int tap0, int 
     }
 }
 
-// the sub-pixel phases of a transposed convolution in one launch (see conv_wgrad_stream_multi_kernel), bf16 pipe
+// Four-tap phases {dyA, dyB} x {0, dxr} (the 4 x 4 transposed convs): a wave's two taps sit in ONE operand row, at
+// columns x and x + dxr.  Walking the positions of a grid row against dxr, the rows read for the unshifted tap at one
+// position ARE the shifted tap's rows at the next: they stay in registers as split fragments, so a chunk requests and
+// splits one tap's operand rows instead of two (the operand's rows are the ones that miss, see wgrad_bf3_body; and the
+// split is half of the VALU work).  At the start of a grid row the shifted tap is outside the image (zero fragments);
+// where it is not — the first chunk of a stream that starts inside a row — its rows are fetched for that chunk alone.
 template <bool HAS_T>
+__device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, const float* __restrict__ A,
+                                                   const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                   const float* __restrict__ G, int g_pitch, float* __restrict__ part,
+                                                   float* __restrict__ db_part, int bid, int nblk, float* comb) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kq = lane >> 4;
+    const SplitSel ssel = make_split_sel();
+    const int tp = w & 1, p = w >> 1;                            // tap pair (operand row dyA / dyB) x row stream
+    constexpr int P = 2;
+    const int npix = g.Hg * g.Wg;
+    const int nchunks = (nimg / 32) * npix;
+    const int nstreams = nblk * P, sid = bid * P + p;
+    const int c_begin = (int)((long)nchunks * sid / nstreams), c_end = (int)((long)nchunks * (sid + 1) / nstreams);
+    // taps 2 tp and 2 tp + 1 share dy; un: the one with dx = 0 (its rows are requested), ur: the shifted one (reused)
+    const int un = g.dx[2 * tp] == 0 ? 0 : 1, ur = 1 - un;
+    const int tn = 2 * tp + un, tr = 2 * tp + ur;
+    const int dy = g.dy[tn], dxr = g.dx[tr];
+    const bool ascending = dxr < 0;                              // walk against the shift
+    const int img_a = g.Hi * g.Wi * g.a_pitch, img_g = g.Ho * g.Wo * g_pitch;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_T) {
+        sc = scaled4(*reinterpret_cast<const float4*>(a_scale + g.a_col[tn] + 4 * i), FOLD_DOWN);
+        sh = scaled4(*reinterpret_cast<const float4*>(a_shift + g.a_col[tn] + 4 * i), FOLD_DOWN);
+    }
+    const unsigned lane_a = (unsigned)(8 * kq * img_a + 4 * i) * 4u, lane_g = (unsigned)(8 * kq * img_g + 4 * i) * 4u;
+
+    struct Desc { int a, sa, go, sg; unsigned flags; };          // flags: 1 = row in image, 2 = shifted tap in image,
+                                                                 //        4 = first position of a grid row walk, 8 = live
+    auto describe = [&](int c, bool live) {
+        Desc d;
+        const int ib = c / npix, pix = c - ib * npix;
+        const int y = pix / g.Wg, xi = pix - y * g.Wg;
+        const int x = ascending ? xi : g.Wg - 1 - xi;
+        const int img = ib * 32, ys = y * g.sy + dy, xs = x * g.sx;
+        const bool row_in = live & ((unsigned)ys < (unsigned)g.Hi) & ((unsigned)xs < (unsigned)g.Wi);
+        const bool sh_in = row_in & ((unsigned)(xs + dxr) < (unsigned)g.Wi);
+        d.a = row_in ? ((img * g.Hi + ys) * g.Wi + xs) * g.a_pitch + g.a_col[tn] : 0;
+        d.sa = row_in ? img_a : 0;
+        const int op = (img * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
+        d.go = live ? op * g_pitch : 0;
+        d.sg = live ? img_g : 0;
+        d.flags = (row_in ? 1u : 0u) | (sh_in ? 2u : 0u) | (xi == 0 ? 4u : 0u) | (live ? 8u : 0u);
+#if CMVAE_ABLATE == 7      // every load hits the same few rows: the compute-side ceiling of this loop
+        d.a = d.go = 0; d.sa = d.sg = 0;
+#elif CMVAE_ABLATE == 71   // ... only the operand's loads do
+        d.a = 0; d.sa = 0;
+#elif CMVAE_ABLATE == 72   // ... only the gradient's
+        d.go = 0; d.sg = 0;
+#endif
+        return d;
+    };
+
+    floatx4 acc[2][16];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[u][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float db_on = (db_part != nullptr && tp == 0) ? 1.f : 0.f;
+
+    float4 rx[8], rg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);      // (finite, whatever is skipped first)
+    // Rows outside the image (and the prefetch past the end of the range) are NOT requested: a dummy request to one
+    // fixed address from every wave that is at a border row funnels through a single L2 channel — at layer 3 that was
+    // ~110 MB through one channel per launch and a third of the kernel's time (the loads are uniform branches; the
+    // registers' stale contents are multiplied by zero).
+    auto issue_x = [&](const Desc& d) {
+        if (!(d.flags & 1u)) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            rx[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A + (d.a + j * d.sa)) + lane_a);
+    };
+    auto issue_g = [&](const Desc& d) {
+        if (!(d.flags & 8u)) return;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            rg[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(G + (d.go + j * d.sg)) + lane_g);
+    };
+    auto folded = [&](float4 (&a)[8], float von) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 f = fold_a_scaled<HAS_T>(rx[j], sc, sh);
+            const floatx2 lo = floatx2{f.x, f.y} * floatx2{von, von}, hi = floatx2{f.z, f.w} * floatx2{von, von};
+            a[j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+    };
+
+    Frag3 xprev[4];
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja) xprev[ja].p[0] = xprev[ja].p[1] = xprev[ja].p[2] = make_uint4(0u, 0u, 0u, 0u);
+    int c = c_begin;
+    Desc cur = describe(c, c < c_end);
+    if (c < c_end && (cur.flags & 2u) && !(cur.flags & 4u)) {
+        // the stream starts inside a grid row: the shifted tap's rows of this first chunk (= the unshifted tap's of the
+        // position before it in the walk)
+        Desc pre = cur;
+        pre.a = cur.a + dxr * g.a_pitch;
+#if CMVAE_ABLATE == 7 || CMVAE_ABLATE == 71      // (the ablation builds zero cur.a: stay inside the tensor)
+        pre.a = 0;
+#endif
+        issue_x(pre);
+        float4 a[8];
+        folded(a, 1.f);
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja) xprev[ja] = split_rows(a, ja, ssel);
+    }
+    issue_x(cur);
+    issue_g(cur);
+    for (; c < c_end; ++c) {
+        const Desc nxt = describe(c + 1, c + 1 < c_end);
+        float4 a[8];
+        folded(a, (cur.flags & 1u) ? 1.f : 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            floatx2 lo = {dbs.x, dbs.y}, hi = {dbs.z, dbs.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lo = __builtin_elementwise_fma(floatx2{rg[j].x, rg[j].y}, floatx2{db_on, db_on}, lo);
+                hi = __builtin_elementwise_fma(floatx2{rg[j].z, rg[j].w}, floatx2{db_on, db_on}, hi);
+            }
+            dbs = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+        Frag3 gB[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) gB[jb] = split_rows(rg, jb, ssel);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_g(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(cur.flags & 2u)) {                                 // uniform: the shifted tap is outside the image here
+#pragma unroll
+            for (int ja = 0; ja < 4; ++ja) xprev[ja].p[0] = xprev[ja].p[1] = xprev[ja].p[2] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        Frag3 xnew[4];
+        xnew[0] = split_rows(a, 0, ssel);
+        __builtin_amdgcn_sched_barrier(0);
+        // stages 0..3: the unshifted tap, the next sub-lattice's fragment split in the gaps of the 24 MFMAs;
+        // stages 4..7: the shifted tap on the fragments kept from the previous position
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja) {
+            if (ja < 3) xnew[ja + 1] = split_rows(a, ja + 1, ssel);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[0][ja * 4 + jb] = mfma16_split6(xnew[ja], gB[jb], acc[0][ja * 4 + jb]);
+            if (ja < 3) {
+#pragma unroll
+                for (int m = 0; m < 14; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja) {
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[1][ja * 4 + jb] = mfma16_split6(xprev[ja], gB[jb], acc[1][ja * 4 + jb]);
+        }
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja) xprev[ja] = xnew[ja];
+        cur = nxt;
+    }
+
+    if (HAS_T) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[u][k] *= FOLD_UP;          // exact: the operand was folded times 2^-60
+    }
+    float* cb = comb + tp * 8192 + lane;
+    if (p == 1) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 64; ++r) cb[(u * 64 + r) * 64] = acc[u][r >> 2][r & 3];
+    }
+    __syncthreads();
+    if (p == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 64; ++r) acc[u][r >> 2][r & 3] += cb[(u * 64 + r) * 64];
+    }
+    __syncthreads();
+    if (db_part) {
+        dbs.x += __shfl_xor(dbs.x, 16); dbs.y += __shfl_xor(dbs.y, 16); dbs.z += __shfl_xor(dbs.z, 16); dbs.w += __shfl_xor(dbs.w, 16);
+        dbs.x += __shfl_xor(dbs.x, 32); dbs.y += __shfl_xor(dbs.y, 32); dbs.z += __shfl_xor(dbs.z, 32); dbs.w += __shfl_xor(dbs.w, 32);
+        if (tp == 0 && kq == 0) *reinterpret_cast<float4*>(&comb[p * 64 + 4 * i]) = dbs;
+        __syncthreads();
+        if (tid < 64) db_part[(long)bid * 64 + tid] = comb[tid] + comb[64 + tid];
+    }
+    if (p == 0) {
+        float* pb = part + (long)bid * 4 * 4096;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = u == 0 ? tn : tr;                      // acc[0]: the unshifted tap, acc[1]: the shifted one
+#pragma unroll
+            for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = 16 * kq + 4 * r + ja;
+                    *reinterpret_cast<float4*>(&pb[t * 4096 + ci * 64 + 4 * i]) =
+                        make_float4(acc[u][ja * 4 + 0][r], acc[u][ja * 4 + 1][r], acc[u][ja * 4 + 2][r], acc[u][ja * 4 + 3][r]);
+                }
+        }
+    }
+}
+
+// the sub-pixel phases of a transposed convolution in one launch (see conv_wgrad_stream_multi_kernel), bf16 pipe
+// ROWS: every phase has four taps in two operand rows (wgrad_bf3_row_body)
+template <bool HAS_T, bool ROWS>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_bf3_multi_kernel(ConvGeomMulti p, int nimg, int db_blocks,
                                                                       const float* __restrict__ A,
                                                                       const float* __restrict__ a_scale,
@@ -1770,9 +1989,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_bf3_multi_kernel(ConvGeomMu
     const int ph = (b >= p.begin[1]) + (b >= p.begin[2]) + (b >= p.begin[3]);          // uniform
     const ConvGeom& g = p.g[ph];
     const int b0 = p.begin[ph];
-    wgrad_bf3_body<HAS_T>(g, 0, g.ntaps, nimg, A, a_scale, a_shift, G, g_pitch, 0, part + (long)b0 * 4 * 4096,
-                          (db_part && b < db_blocks) ? db_part + (long)b0 * 64 : nullptr, b - b0,
-                          p.begin[ph + 1] - b0, 4, comb);
+    if (ROWS)
+        wgrad_bf3_row_body<HAS_T>(g, nimg, A, a_scale, a_shift, G, g_pitch, part + (long)b0 * 4 * 4096,
+                                  (db_part && b < db_blocks) ? db_part + (long)b0 * 64 : nullptr, b - b0,
+                                  p.begin[ph + 1] - b0, comb);
+    else
+        wgrad_bf3_body<HAS_T>(g, 0, g.ntaps, nimg, A, a_scale, a_shift, G, g_pitch, 0, part + (long)b0 * 4 * 4096,
+                              (db_part && b < db_blocks) ? db_part + (long)b0 * 64 : nullptr, b - b0,
+                              p.begin[ph + 1] - b0, 4, comb);
 }
 
 template <bool HAS_T>
@@ -2375,8 +2599,21 @@ extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, c
     float* db_part = (float*)((char*)workspace + align_up((size_t)wgrad_grid(1 << 30) * 4 * 4096 * sizeof(float)));
     float* dbp = db ? db_part : nullptr;
     if (bf3) {
-        if (a_scale) hipLaunchKernelGGL(conv_wgrad_bf3_multi_kernel<true>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
-        else hipLaunchKernelGGL(conv_wgrad_bf3_multi_kernel<false>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
+        // four taps per phase, as two operand rows x {unshifted, shifted by one column} in that order, same operand
+        // columns: the kernel that keeps the unshifted tap's fragments for the shifted one
+        bool rows4 = true;
+        for (int k = 0; k < ngeom; ++k) {
+            const ConvGeom& g = p.g[k];
+            rows4 = rows4 && g.ntaps == 4 && g.sx == 1 && g.Wg == g.Wi;
+            for (int t = 0; rows4 && t < 4; t += 2) {
+                const int d0 = g.dx[t], d1 = g.dx[t + 1];
+                rows4 = g.dy[t] == g.dy[t + 1] && g.a_col[t] == g.a_col[t + 1] && ((d0 == 0 && (d1 == 1 || d1 == -1)) || (d1 == 0 && (d0 == 1 || d0 == -1)));
+            }
+        }
+#define CMVAE_WG_BF3(HAS_T, ROWS) hipLaunchKernelGGL((conv_wgrad_bf3_multi_kernel<HAS_T, ROWS>), dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp)
+        if (a_scale) { if (rows4) CMVAE_WG_BF3(true, true); else CMVAE_WG_BF3(true, false); }
+        else { if (rows4) CMVAE_WG_BF3(false, true); else CMVAE_WG_BF3(false, false); }
+#undef CMVAE_WG_BF3
         if (int e = check_launch("conv_wgrad_bf3_multi_kernel")) return e;
         hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(4 * 64 + 1, ngeom), dim3(1024), 0, st, part, o, dW, dbp, db, used, 0);
         return check_launch("wgrad_reduce_multi_kernel");

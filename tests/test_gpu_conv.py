@@ -171,6 +171,65 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
         assert torch.equal(da, da2)
 
 
+def test_bf16_pipe_products_are_fp32_products(device):
+    """The big decoder launches run their fp32 products on the bf16 matrix pipe: each operand is the exact sum of three
+    bf16 pieces and six of the nine piece products are accumulated in fp32 (csrc/conv_gemm.hip: mfma_split6).  What
+    is dropped is below 2^-24 of |a b|, fp32's own rounding, so the results must be as close to float64 as an fp32
+    computation is.  Layer-3-shaped transposed conv (64 -> 64, k 4, stride 2) over 1024 images of 14 x 14 — forward
+    (802 816 rows), data gradient (200 704 rows, three accumulating passes) and weight gradient (32-image chunks) all
+    take that path — against float64 on the CPU, next to PyTorch's own fp32 results on the same GPU."""
+    from cmvae_amd import conv
+    n, Hi, k = 1024, 14, 4
+    Ho = conv.convT_out(Hi, k)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, 64, Hi, Hi, generator=g)
+    sc = torch.rand(64, generator=g) + 0.5
+    sh = torch.randn(64, generator=g) * 0.3
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    w = torch.randn(64, 64, k, k, generator=g) * 0.1
+    gy = torch.randn(n, 64, Ho, Ho, generator=g)
+    xd, gyd = nhwc(x).to(device), nhwc(gy).to(device)
+    scd, shd = sc.to(device), sh.to(device)
+    # float64 references: forward and data gradient on a few images, the weight gradient over all of them
+    sel = torch.arange(0, n, 171)
+    y64 = F.conv_transpose2d(a[sel].double(), w.double(), None, 2, 1)
+    da64 = F.conv2d(gy[sel].double(), w.double(), None, 2, 1)
+    a64 = a.double().requires_grad_(False)
+    w64 = w.double().requires_grad_(True)
+    F.conv_transpose2d(a64, w64, None, 2, 1).backward(gy.double())
+    dw64 = w64.grad
+    # PyTorch fp32 on the GPU
+    ag, wg = a.to(device), w.to(device).requires_grad_(True)
+    yt = F.conv_transpose2d(ag, wg, None, 2, 1)
+    yt.backward(gy.to(device))
+    dat = F.conv2d(gy.to(device)[sel.to(device)], w.to(device), None, 2, 1)
+    # this library
+    wprep = w.permute(2, 3, 1, 0).contiguous().view(k * k, 64, 64).to(device)
+    phases = [conv.geom_convT_phase(n, Hi, Hi, k, py, px, pixel_major=True) for py in (0, 1) for px in (0, 1)]
+    out = torch.full((n * Ho * Ho, 64), float('nan'), device=device)
+    conv.conv_gemm_multi([ge for ge, _ in phases], xd, wprep, out, a_scale=scd, a_shift=shd)
+    dW = torch.full((64, 64, k, k), float('nan'), device=device)
+    conv.conv_wgrad_multi([ge for ge, _ in phases], xd, gyd, dW, [t for _, t in phases], s_ci=64 * k * k, s_co=k * k,
+                          a_scale=scd, a_shift=shd)
+    gd, _ = conv.geom_convT_dgrad(n, Hi, Hi, k, pixel_major=True)
+    wtd = w.permute(2, 3, 0, 1).contiguous().to(device)
+    da = torch.full((n * Hi * Hi, 64), float('nan'), device=device)
+    fold = (scd, shd, torch.zeros(64, device=device), torch.ones(64, device=device))
+    conv.conv_gemm_bnbwd(gd, gyd, wtd, da, xd, fold)
+
+    def err(v, ref):
+        return float((v.double().cpu() - ref).abs().max() / ref.abs().max())
+    mine = {'forward': err(from_nhwc(out.cpu(), n, Ho, Ho)[sel], y64), 'dgrad': err(from_nhwc(da.cpu(), n, Hi, Hi)[sel], da64),
+            'wgrad': err(dW, dw64)}
+    torch32 = {'forward': err(yt.detach()[sel.to(device)], y64), 'dgrad': err(dat, da64), 'wgrad': err(wg.grad, dw64)}
+    print('  max |error| / max |float64 value|: this library %s; torch fp32 on the GPU %s' % (mine, torch32))
+    for key in mine:
+        # at least as close to float64 as an fp32 computation: 1e-6 of scale is a few fp32 roundings of a 1024-term
+        # sum (a bf16-only product would sit near 4e-3, a two-piece split near 1e-5)
+        assert mine[key] < 1e-6, (key, mine[key])
+        assert mine[key] < 2.0 * torch32[key] + 2e-7, (key, mine[key], torch32[key])
+
+
 def test_dgrad_bn_sums_epilogue_weight_stationary_kernel(device):
     """Layer-2 shape of the training step (9-tap data gradient, >= 196608 rows: the eight-wave weight-stationary
     kernel): gradient equal to the plain launch, sums equal to the separate reduction pass."""
