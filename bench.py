@@ -35,6 +35,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # bf16 MFMA dense peak (MI355X_MICROARCH.md, matrix cores)
+# fp32 products on the bf16 pipe cost six bf16 MFMA products each (three-piece split, csrc/conv_gemm.hip): the pipe's peak
+# in fp32-equivalent (algorithmic) FLOP/s
+BF16_PIPE_F32_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 EM_ITERS, QUERY = 10, 15
 PMC_CONFIG = 'o20'             # which committed profiles/r*_<config>_pmc_traffic.json the roofline traffic is read from
 WAY, SAMPLE, MC, B_PER_GPU = 20, 300, 32, 4        # the default (o20) shape, for the probes under tools/
@@ -180,11 +184,26 @@ def _template_args(kernel_name):
     return [a.strip() for a in kernel_name[i + 1:j].split(',')]
 
 
-def _is_conv_gemm(k):
-    """Kernel names of the conv / conv-transpose / data-gradient launches roofline_conv_gemm times:
-    conv_gemm_wstat_multi_kernel, conv_gemm_wstat_kernel<ACT = 0, ...> (an activation marks an nn.Linear launch),
-    conv_gemm_direct_kernel<ACT, LINEAR = false, ...>, conv_gemm_kernel."""
+def _is_bf16_pipe(k):
+    """Kernel names of the launches whose fp32 products run on the bf16 matrix pipe: the BF3 instantiations of the
+    weight-stationary kernels (last template argument) and the bf16-pipe weight gradient."""
     a = _template_args(k)
+    if k.startswith('conv_wgrad_bf3_multi_kernel'):
+        return True
+    if k.startswith('conv_gemm_wstat_multi_kernel'):
+        return len(a) == 4 and a[3] == 'true'
+    if k.startswith('conv_gemm_wstat_kernel'):
+        return len(a) == 7 and a[6] == 'true'
+    return False
+
+
+def _is_conv_gemm(k):
+    """Kernel names of the fp32-MFMA conv / conv-transpose / data-gradient launches: conv_gemm_wstat_multi_kernel,
+    conv_gemm_wstat_kernel<ACT = 0, ...> (an activation marks an nn.Linear launch), conv_gemm_direct_kernel<ACT,
+    LINEAR = false, ...>, conv_gemm_kernel — without the bf16-pipe instantiations."""
+    a = _template_args(k)
+    if _is_bf16_pipe(k):
+        return False
     if k.startswith('conv_gemm_wstat_multi_kernel') or k.startswith('conv_gemm_kernel'):
         return True
     if k.startswith('conv_gemm_wstat_kernel'):
@@ -203,21 +222,22 @@ def _is_linear_gemm(k):
     return False
 
 
-def pmc_traffic_conv_gemm():
-    return pmc_traffic(_is_conv_gemm)
-
-
 def roofline_conv_gemm(step_fn):
-    """Dominant kernel family of the Omniglot step: the fp32-MFMA gather-GEMM (all decoder / encoder convs and their
-    data gradients; the four sub-pixel phases of a transposed conv are one launch).  Every launch of one extra,
-    untimed training step is bracketed by HIP events on the launch stream; achieved = sum of algorithmic FLOPs / sum
-    of launch durations."""
+    """Dominant kernels of the Omniglot step: the gather-GEMM contractions of the conv stacks.  Every launch of one
+    extra, untimed training step is bracketed by HIP events on the launch stream; per group, achieved = sum of
+    algorithmic FLOPs / sum of launch durations.  Two groups, by the matrix pipe the products run on:
+      * the decoder's big layers (forward of the four sub-pixel phases, data gradient, weight gradient) run fp32
+        products as six bf16 MFMA products of exact three-piece splits: priced against the bf16 dense peak / 6, with
+        the fraction of the fp32-MFMA peak next to it (it can exceed 1: that pipe is not the one in use);
+      * every other conv launch runs on the fp32 MFMA: priced against its peak.
+    Returns (dominant group, other group)."""
     import torch
     from cmvae_amd import conv
-    rec = []
-    origs = {n: getattr(conv, n) for n in ('conv_gemm', 'conv_gemm_multi', 'conv_gemm_bnbwd')}
+    rec = {'bf16': [], 'f32': []}
+    names = ('conv_gemm', 'conv_gemm_multi', 'conv_gemm_bnbwd', 'conv_wgrad_multi')
+    origs = {n: getattr(conv, n) for n in names}
 
-    def timed(name, flops_of):
+    def timed(name, flops_of, group_of):
         orig = origs[name]
 
         def f(*args, **kw):
@@ -226,31 +246,56 @@ def roofline_conv_gemm(step_fn):
             e0.record()
             r = orig(*args, **kw)
             e1.record()
-            rec.append((e0, e1, flops_of(*args, **kw)))
+            grp = group_of(*args, **kw)
+            if grp:
+                rec[grp].append((e0, e1, flops_of(*args, **kw)))
             return r
         return f
 
-    conv.conv_gemm = timed('conv_gemm', lambda g, *a, **kw: useful_flops(g, kw.get('n_col_blocks', 1)))
-    conv.conv_gemm_multi = timed('conv_gemm_multi', lambda gs, *a, **kw: sum(useful_flops(g, 1) for g in gs))
-    conv.conv_gemm_bnbwd = timed('conv_gemm_bnbwd', lambda g, *a, **kw: useful_flops(g, 1))
+    pipe = lambda kind, gs: 'bf16' if conv.on_bf16_pipe(kind, gs) else 'f32'      # noqa: E731
+    conv.conv_gemm = timed('conv_gemm', lambda g, *a, **kw: useful_flops(g, kw.get('n_col_blocks', 1)),
+                           lambda g, *a, **kw: 'f32')
+    conv.conv_gemm_multi = timed('conv_gemm_multi', lambda gs, *a, **kw: sum(useful_flops(g, 1) for g in gs),
+                                 lambda gs, *a, **kw: pipe('multi', gs))
+    conv.conv_gemm_bnbwd = timed('conv_gemm_bnbwd', lambda g, *a, **kw: useful_flops(g, 1),
+                                 lambda g, *a, **kw: pipe('bnbwd', [g]))
+    # weight gradients: the bf16-pipe launches belong to the dominant group; the fp32 streaming launches are left out
+    # of the fp32 group (they were never part of it: it prices the forward / data-gradient kernel family)
+    conv.conv_wgrad_multi = timed('conv_wgrad_multi', lambda gs, *a, **kw: sum(useful_flops(g, 1) for g in gs),
+                                  lambda gs, *a, **kw: 'bf16' if conv.on_bf16_pipe('wgrad_multi', gs) else None)
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
         for n, f in origs.items():
             setattr(conv, n, f)
-    total_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-    total_flops = sum(f for _, _, f in rec)
-    achieved = total_flops / (total_ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic_conv_gemm()
-    return {'kernel': 'conv_gemm_wstat(_multi)_kernel + conv_gemm_direct_kernel (conv / conv-transpose / data-gradient '
-                      'launches)',
-            'bound': 'mfma', 'achieved': round(achieved, 2),
-            'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': src,
-            'launches_per_step': len(rec), 'avg_launch_us': round(total_ms * 1e3 / len(rec), 1),
-            'algorithmic_gflop_per_launch': round(total_flops / len(rec) / 1e9, 2),
-            'share_of_step_ms': round(total_ms, 2)}
+
+    def group(key, kernel, select, peak, extra):
+        r = rec[key]
+        if not r:
+            return None
+        total_ms = sum(a.elapsed_time(b) for a, b, _ in r)
+        total_flops = sum(f for _, _, f in r)
+        achieved = total_flops / (total_ms * 1e-3) / 1e12
+        traffic, src = pmc_traffic(select)
+        d = {'kernel': kernel, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1),
+             'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
+             'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': src, 'launches_per_step': len(r),
+             'avg_launch_us': round(total_ms * 1e3 / len(r), 1),
+             'algorithmic_gflop_per_launch': round(total_flops / len(r) / 1e9, 2), 'share_of_step_ms': round(total_ms, 2)}
+        d.update(extra(achieved))
+        return d
+
+    bf = group('bf16', 'conv_gemm_wstat(_multi)_kernel<.., BF3> + conv_wgrad_bf3_multi_kernel (decoder layers 2-3: forward, '
+               'data gradient, weight gradient; fp32 products as six bf16 MFMA products)', _is_bf16_pipe,
+               BF16_PIPE_F32_EQUIV_PEAK_TFLOPS,
+               lambda a: {'achieved_unit_note': 'algorithmic (fp32) FLOP/s', 'peak_note': 'bf16 dense MFMA peak 2500 / 6 '
+                          'products per fp32 product', 'frac_of_fp32_mfma_peak': round(a / MFMA_F32_PEAK_TFLOPS, 4)})
+    f32 = group('f32', 'conv_gemm_wstat(_multi)_kernel + conv_gemm_direct_kernel on the fp32 MFMA (the other conv / '
+                'conv-transpose / data-gradient launches)', _is_conv_gemm, MFMA_F32_PEAK_TFLOPS, lambda a: {})
+    if bf is None:
+        return f32, None
+    return bf, f32
 
 
 def roofline_linear(step_fn):
@@ -657,10 +702,13 @@ def main():
     # roofline of the dominant kernel: one extra, untimed, instrumented training step (all ranks take part: the step
     # contains the BatchNorm-statistics and gradient all-reduces); the sweep config reports the EM pass
     if step is not None:
-        roof = roofline_conv_gemm(lambda: eager_step(0)) if cfg['variant'] == 'omniglot' else \
-            roofline_linear(lambda: eager_step(0))      # launch by launch: the eager step, also where the step is replayed
+        roof_more = None
+        if cfg['variant'] == 'omniglot':
+            roof, roof_more = roofline_conv_gemm(lambda: eager_step(0))
+        else:
+            roof = roofline_linear(lambda: eager_step(0))      # launch by launch: the eager step, also where the step is replayed
     else:
-        roof = None
+        roof, roof_more = None, None
     if rank == 0:
         em_shapes = [('train %s' % args.config, (Bl, N, way))]
         if args.config in ('o20', 'ce_sweep', 'mi'):
@@ -670,7 +718,7 @@ def main():
             roof = em_roof[-1]
             em_roof = em_roof[:-1]
         out['roofline'] = roof
-        out['roofline_other'] = em_roof
+        out['roofline_other'] = ([roof_more] if roof_more else []) + em_roof
         note('roofline measurements done; starting cpu baseline')
         if world == 1 and not args.no_cpu_baseline:
             # the host's cores: every one of them unless the environment fixes the thread count (the GPU boxes of this

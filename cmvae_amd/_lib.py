@@ -116,6 +116,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     'cmvae_conv_gemm_bnbwd': (c_int, [_PG] + [c_void_p] * 10),
     'cmvae_conv_gemm_multi_grid': (c_int, []),
+    'cmvae_conv_bf16_pipe_min_rows': (c_int, []),
     'cmvae_conv_gemm_multi': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
     'cmvae_conv_wgrad_workspace_bytes': (c_size_t, [c_int]),

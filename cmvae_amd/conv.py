@@ -141,6 +141,29 @@ def conv_gemm_multi(geoms, A, Wt, out, bias=None, a_scale=None, a_shift=None, st
     return part
 
 
+@functools.lru_cache(maxsize=None)
+def bf16_pipe_min_rows():
+    return lib.cmvae_conv_bf16_pipe_min_rows()
+
+
+def on_bf16_pipe(kind, geoms):
+    """Whether a launch runs its fp32 products on the bf16 matrix pipe (three-piece split, six products) — the rules
+    of csrc/conv_gemm.hip restated for measurement code (bench.py groups its roofline by pipe) and tests.
+    kind: 'multi' (conv_gemm_multi), 'bnbwd' (conv_gemm_bnbwd), 'wgrad_multi' (conv_wgrad_multi)."""
+    gs = list(geoms)
+    g0 = gs[0]
+    npix = g0.Hg * g0.Wg
+    pm = bool(g0.pixel_major) and npix > 0 and g0.rows_total // npix >= 64
+    rows = sum(g.rows_total for g in gs)
+    if kind == 'multi':
+        return pm and rows >= bf16_pipe_min_rows()
+    if kind == 'bnbwd':
+        return pm and rows >= bf16_pipe_min_rows() and (g0.ntaps <= 6 or 9 < g0.ntaps <= 18)
+    if kind == 'wgrad_multi':
+        return npix > 0 and (g0.rows_total // npix) % 32 == 0 and rows >= bf16_pipe_min_rows()
+    raise ValueError(kind)
+
+
 def _wgrad_ws(rows, device):
     return _workspace.get(lib.cmvae_conv_wgrad_workspace_bytes(rows), device, 'conv_wgrad')
 

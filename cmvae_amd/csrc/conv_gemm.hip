@@ -2204,6 +2204,8 @@ static int wgrad_grid(int rows_total) {
 extern "C" int cmvae_conv_gemm_grid(int rows_total, int n_col_blocks) {
     cmvae::clear_stale_error(); return gemm_grid(rows_total, n_col_blocks); }
 
+extern "C" int cmvae_conv_bf16_pipe_min_rows(void) { cmvae::clear_stale_error(); return bf3_min_rows(); }
+
 extern "C" int cmvae_conv_gemm_multi_grid(void) { cmvae::clear_stale_error(); return 2 * compute_units(); }
 
 extern "C" int cmvae_conv_gemm_multi(const cmvae_conv_geom* geoms, int ngeom, const float* A, const float* Wt,

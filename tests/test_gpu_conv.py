@@ -107,7 +107,7 @@ def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
         om = torch.full((n * Ho * Ho, 64), float('nan'), device=device)
         pmulti = conv.conv_gemm_multi(geoms, xd, wprep, om, bias=bd, a_scale=scd if fold else None,
                                       a_shift=shd if fold else None, stats=True)
-        if pm and n >= 64 and n * Ho * Ho >= 3 * 256 * 256:
+        if conv.on_bf16_pipe('multi', geoms):
             # large pixel-major launches run their products on the bf16 pipe (three-piece split, six products per
             # fp32 product: csrc/conv_gemm.hip mfma_split6): the same sums to fp32 rounding, not bit for bit
             assert rel_err(om, o1) < 1e-6 and float((om - o1).abs().max()) < 2e-6 * float(o1.abs().max())
