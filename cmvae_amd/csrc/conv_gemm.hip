@@ -845,14 +845,15 @@ __device__ __forceinline__ void wstat_body(
     // moment, on neighbouring positions of one image group — a working set of a few operand positions that its L2
     // holds — instead of on one position of many groups, where every gathered row was an L2 miss.
     const int gimg = PM ? g.pm_nimg / BMT : 0;                    // image groups
+    const int gimg_d = gimg > 0 ? gimg : 1;                       // (divisor where gimg > 0 has been tested)
     // (not for images of few positions: when the XCD's stride nblk / 8 is a multiple of the positions per image, a
     // workgroup meets the same position in every group, and border positions have fewer taps than inner ones — the
     // 16-position data gradient of layer 2 took 400 us instead of 310; rotating the positions per group cured that
     // and cost the 49-position layers 10 %)
     const bool swz = PM && g.xcd_order && gridDim.y == 1 && (nblk & 7) == 0 && ((stats_bid - bid) & 7) == 0 &&
-                     gimg > 0 && g.pm_nimg % BMT == 0 && ntiles % gimg == 0 && ntiles / gimg >= 32 &&
-                     (nblk >> 3) % (ntiles / gimg) != 0;
-    const int npos = swz ? ntiles / gimg : 1;
+                     gimg > 0 && g.pm_nimg % BMT == 0 && ntiles % gimg_d == 0 && ntiles / gimg_d >= 32 &&
+                     (nblk >> 3) % (ntiles / gimg_d) != 0;
+    const int npos = swz ? ntiles / gimg_d : 1;
     int v = bid, v_end = ntiles, v_step = nblk;
     if (swz) {
         const int x = bid & 7;
