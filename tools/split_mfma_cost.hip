@@ -12,6 +12,8 @@
 //   MODE 0: fp32 MFMA, 32-row wave tile (64 MFMAs per step)            — what ships
 //   MODE 1: split in registers + bf16 MFMA, 32-row wave tile (48 MFMAs per step)
 //   MODE 2: the same with a 64-row wave tile (two operand rows per lane, 96 MFMAs per step, weight fragments shared)
+//   MODE 4: MODE 1 with v_mfma_f32_16x16x32_bf16 (2 x 4 tiles of 16 x 16 per wave, 96 MFMAs per step): the shape the chip
+//           clocks higher on
 //   MODE 3: MODE 1 software-pipelined: the split of step s + 1 is interleaved with the MFMAs of step s (three VALU per
 //           MFMA gap, __builtin_amdgcn_sched_group_barrier), the loads of step s + 2 follow the split that freed
 //           their registers — a bf16 MFMA holds the vector issue for 8 of its 32 cycles only, the rest can hide VALU
@@ -80,6 +82,17 @@ __device__ __forceinline__ floatx16 mfma6(const Frag3& a, const Frag3& b, floatx
     return c;
 }
 
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx4 mfma6_16(const Frag3& a, const Frag3& b, floatx4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[2]), as_bf(b.p[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[0]), as_bf(b.p[2]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[1]), as_bf(b.p[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[1]), as_bf(b.p[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[0]), as_bf(b.p[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[0]), as_bf(b.p[0]), c, 0, 0, 0);
+    return c;
+}
+
 // A: [rows][64] fp32, W: [64 co][64 ci] fp32, out: [rows][64].  Every wave works on its own rows; `steps` tap steps
 // re-read the same rows (the timing build) or steps == 1 (the check).
 template <int MODE>
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void k(const float* __restr
             const int co = e >> 5, c = 2 * (e & 31);
             const Split3 s = split_pair(W[co * 64 + c], W[co * 64 + c + 1], ssel);
             const int kk = c >> 3, hh = (c >> 2) & 1, j = c & 3;
-            const int pos = 16 * (kk >> 1) + 8 * hh + 4 * (kk & 1) + j;
+            const int pos = MODE == 4 ? c : 16 * (kk >> 1) + 8 * hh + 4 * (kk & 1) + j;      // MODE 4: natural order
             *reinterpret_cast<unsigned*>(&Wp[(0 * 64 + co) * LDB + pos]) = s.p1;
             *reinterpret_cast<unsigned*>(&Wp[(1 * 64 + co) * LDB + pos]) = s.p2;
             *reinterpret_cast<unsigned*>(&Wp[(2 * 64 + co) * LDB + pos]) = s.p3;
@@ -123,6 +136,56 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 2) void k(const float* __restr
     };
     load(0);
     const long long t0 = clock64();
+    if (MODE == 4) {
+        const int m = lane & 15, kg = lane >> 4;
+        floatx4 c4[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) c4[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+        float4 r4[8];
+        auto load4 = [&](int s) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const float* p = A + (((row0 + 16 * mi + m) * 64 + (long)s * 8192) & a_mask) + 32 * ks + 8 * kg;
+                    r4[(mi * 2 + ks) * 2] = *reinterpret_cast<const float4*>(p);
+                    r4[(mi * 2 + ks) * 2 + 1] = *reinterpret_cast<const float4*>(p + 4);
+                }
+        };
+        load4(0);
+        const __bf16* Wp = reinterpret_cast<const __bf16*>(smem);
+        for (int s = 0; s < steps; ++s) {
+            Frag3 fa[2][2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = split8(r4[(mi * 2 + ks) * 2], r4[(mi * 2 + ks) * 2 + 1], ssel);
+            load4(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    Frag3 b;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b.p[pl] = *reinterpret_cast<const uint4*>(&Wp[(pl * 64 + 16 * ni + m) * LDB + 32 * ks + 8 * kg]);
+                    c4[0][ni] = mfma6_16(fa[0][ks], b, c4[0][ni]);
+                    c4[1][ni] = mfma6_16(fa[1][ks], b, c4[1][ni]);
+                }
+        }
+        const long long t1 = clock64();
+        if (lane == 0 && cycles) cycles[blockIdx.x * 4 + w] = t1 - t0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(row0 + 16 * mi + 4 * kg + r) * 64 + 16 * ni + m] = c4[mi][ni][r];
+        return;
+    }
     if (MODE == 3) {
         Frag3 fa[4];
 #pragma unroll
@@ -280,5 +343,6 @@ int main(int argc, char** argv) {
     run<1>(dA, dW, dO, dC, hA, hW, 1024);
     run<2>(dA, dW, dO, dC, hA, hW, 1024);
     run<3>(dA, dW, dO, dC, hA, hW, 1024);
+    run<4>(dA, dW, dO, dC, hA, hW, 1024);
     return 0;
 }
