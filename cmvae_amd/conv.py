@@ -149,7 +149,7 @@ def bf16_pipe_min_rows():
 def on_bf16_pipe(kind, geoms):
     """Whether a launch runs its fp32 products on the bf16 matrix pipe (three-piece split, six products) — the rules
     of csrc/conv_gemm.hip restated for measurement code (bench.py groups its roofline by pipe) and tests.
-    kind: 'multi' (conv_gemm_multi), 'bnbwd' (conv_gemm_bnbwd), 'wgrad_multi' (conv_wgrad_multi)."""
+    kind: 'multi' (conv_gemm_multi), 'bnbwd' (conv_gemm_bnbwd), 'wgrad_multi' (conv_wgrad_multi: four-tap phases)."""
     gs = list(geoms)
     g0 = gs[0]
     npix = g0.Hg * g0.Wg
@@ -160,7 +160,15 @@ def on_bf16_pipe(kind, geoms):
     if kind == 'bnbwd':
         return pm and rows >= bf16_pipe_min_rows() and (g0.ntaps <= 6 or 9 < g0.ntaps <= 18)
     if kind == 'wgrad_multi':
-        return npix > 0 and (g0.rows_total // npix) % 32 == 0 and rows >= bf16_pipe_min_rows()
+        def rows4(g):       # four taps: two operand rows x {unshifted, shifted by one column}
+            if g.ntaps != 4 or g.sx != 1 or g.Wg != g.Wi:
+                return False
+            for t in (0, 2):
+                d = sorted((g.dx[t], g.dx[t + 1]), key=abs)
+                if g.dy[t] != g.dy[t + 1] or g.a_col[t] != g.a_col[t + 1] or d[0] != 0 or abs(d[1]) != 1:
+                    return False
+            return True
+        return npix > 0 and (g0.rows_total // npix) % 32 == 0 and rows >= bf16_pipe_min_rows() and all(rows4(g) for g in gs)
     raise ValueError(kind)
 
 

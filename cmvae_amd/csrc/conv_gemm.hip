@@ -1520,14 +1520,15 @@ __device__ __forceinline__ void wgrad_stream_body(const ConvGeom& g, int tap0, i
 
 // ---------------------------------------------------------------------------- weight gradient on the bf16 pipe
 // The streaming kernel above with its products on the bf16 matrix pipe (mfma_split6's scheme, here with
-// v_mfma_f32_16x16x32_bf16: k = 8 (lane >> 4) + e, e = 0..7).  A chunk is 32 images at one grid position; lane (i, kg)
-// loads channels 4i .. 4i+3 of images 8 kg .. 8 kg + 7 (eight 16-byte loads per operand, each instruction 4 x 256
-// contiguous bytes), so component ja of its eight registers IS the A fragment of sub-lattice ja and component jb of the
-// gradient's the B fragment of jb — split into three bf16 planes in registers, no transposition anywhere.  The
-// accumulator layout, the combination of the row streams and the partials are those of wgrad_stream_body.
-// One workgroup per CU (512 registers per lane: 128 accumulators, both operands' raw rows of the next chunk in
-// flight, the gradient's twelve fragment registers x 4): the split of one fragment is interleaved with the MFMAs of the
-// previous one.
+// v_mfma_f32_16x16x32_bf16: k = 8 (lane >> 4) + e, e = 0..7), for the four-tap phases of the 4 x 4 transposed convs.
+// A chunk is 32 images at one grid position; lane (i, kg) loads channels 4i .. 4i+3 of images 8 kg .. 8 kg + 7 (eight
+// 16-byte loads per operand, each instruction 4 x 256 contiguous bytes), so component ja of its eight registers IS the
+// A fragment of sub-lattice ja and component jb of the gradient's the B fragment of jb — split into three bf16 planes
+// in registers, no transposition anywhere.  The accumulator layout, the combination of the row streams and the
+// partials are those of wgrad_stream_body.  One workgroup per CU (512 registers per lane: 128 accumulators, the raw
+// rows of the next chunk in flight, 3 x 48 fragment registers): the split of one fragment is interleaved with the MFMAs
+// of the previous one.  (Phases with 1 / 2 taps — the 3 x 3 transposed conv — stay on the fp32 streaming kernel: a
+// general two-taps-per-wave version of this kernel ran layer 2 in 350 us against 298.)
 __device__ __forceinline__ floatx4 mfma16_split6(const Frag3& a, const Frag3& b, floatx4 c) {       // small terms first
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[2]), as_bf(b.p[0]), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(a.p[0]), as_bf(b.p[2]), c, 0, 0, 0);
@@ -1549,219 +1550,10 @@ __device__ __forceinline__ Frag3 split_rows(const float4 (&r)[8], int j, const S
     return f;
 }
 
-template <bool HAS_T>
-__device__ __forceinline__ void wgrad_bf3_body(const ConvGeom& g, int tap0, int nt, int nimg,
-                                               const float* __restrict__ A, const float* __restrict__ a_scale,
-                                               const float* __restrict__ a_shift, const float* __restrict__ G,
-                                               int g_pitch, int g_col, float* __restrict__ part,
-                                               float* __restrict__ db_part, int bid, int nblk, int nt_stride,
-                                               float* comb) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 15, kq = lane >> 4;
-    const SplitSel ssel = make_split_sel();
-    const bool split = nt > 2;                                   // two tap pairs x two row streams, else four row streams
-    const int tp = split ? (w & 1) : 0;
-    const int p = split ? (w >> 1) : w;
-    const int P = split ? 2 : 4;
-    const int npix = g.Hg * g.Wg;
-    const int nchunks = (nimg / 32) * npix;
-    const int nstreams = nblk * P, sid = bid * P + p;
-    const int c_begin = (int)((long)nchunks * sid / nstreams), c_end = (int)((long)nchunks * (sid + 1) / nstreams);
-    const int t_u[2] = {split ? tp : 0, split ? 3 - tp : 1};     // (the pairing of wgrad_stream_body)
-    const int img_a = g.Hi * g.Wi * g.a_pitch, img_g = g.Ho * g.Wo * g_pitch;
-
-    float4 sc[2], sh[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        sc[u] = make_float4(1.f, 1.f, 1.f, 1.f); sh[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (HAS_T && t_u[u] < nt) {
-            sc[u] = scaled4(*reinterpret_cast<const float4*>(a_scale + g.a_col[tap0 + t_u[u]] + 4 * i), FOLD_DOWN);
-            sh[u] = scaled4(*reinterpret_cast<const float4*>(a_shift + g.a_col[tap0 + t_u[u]] + 4 * i), FOLD_DOWN);
-        }
-    }
-    // the lane's part of every address, in bytes and unsigned: scalar base + one 32-bit VGPR offset per load
-    const unsigned lane_a = (unsigned)(8 * kq * img_a + 4 * i) * 4u, lane_g = (unsigned)(8 * kq * img_g + 4 * i) * 4u;
-    auto describe = [&](int ib, int y, int x, bool live) {
-        ChunkDesc d;
-        const int img = ib * 32;
-        const int ys = y * g.sy, xs = x * g.sx;
-        d.valid = live ? 4u : 0u;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            bool in = false;
-            int off = 0;
-            if (t_u[u] < nt) {
-                const int t = tap0 + t_u[u];
-                const int dy = g.dy[t], dx = g.dx[t];
-                in = live & ((unsigned)(ys + dy) < (unsigned)g.Hi) & ((unsigned)(xs + dx) < (unsigned)g.Wi);
-                off = ((img * g.Hi + ys + dy) * g.Wi + xs + dx) * g.a_pitch + g.a_col[t];
-            }
-            d.a[u] = in ? off : 0;
-            d.sa[u] = in ? img_a : 0;                            // step between consecutive images
-            d.valid |= in ? (1u << u) : 0u;
-        }
-        const int op = (img * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
-        d.go = live ? op * g_pitch + g_col : 0;
-        d.sg = live ? img_g : 0;
-#if CMVAE_ABLATE == 7      // every operand load hits the same few rows: the compute-side ceiling of this loop
-        d.a[0] = d.a[1] = d.go = 0; d.sa[0] = d.sa[1] = d.sg = 0;
-#elif CMVAE_ABLATE == 71   // ... only the operand's loads do
-        d.a[0] = d.a[1] = 0; d.sa[0] = d.sa[1] = 0;
-#elif CMVAE_ABLATE == 72   // ... only the gradient's
-        d.go = 0; d.sg = 0;
-#endif
-        return d;
-    };
-
-    floatx4 acc[2][16];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[u][k] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float db_on = (db_part != nullptr && tp == 0) ? 1.f : 0.f;
-
-    float4 rx[2][8], rg[8];
-    auto issue_x = [&](int u, const ChunkDesc& d) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            rx[u][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A + (d.a[u] + j * d.sa[u])) + lane_a);
-    };
-    auto issue_g = [&](const ChunkDesc& d) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            rg[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(G + (d.go + j * d.sg)) + lane_g);
-    };
-
-    int c = c_begin;
-    int ib = c / npix;
-    int y, x;
-    { const int pix = c - ib * npix; y = pix / g.Wg; x = pix - y * g.Wg; }
-    ChunkDesc cur = describe(ib, y, x, c < c_end);
-    issue_x(0, cur);
-    issue_x(1, cur);
-    issue_g(cur);
-    for (; c < c_end; ++c) {
-        if (++x == g.Wg) { x = 0; if (++y == g.Hg) { y = 0; ++ib; } }
-        const ChunkDesc nxt = describe(ib, y, x, c + 1 < c_end);
-        // Both taps' operand rows folded, and the next chunk's requested into the freed registers at once: the operand
-        // rows are the ones that miss (re-read rows at shifted positions; the gradient streams), measured +350 us of
-        // stall at layer 3 against none for the gradient's.  Then the bias-gradient sum and the four B fragments, and
-        // the next chunk's gradient rows.  The requests are pinned: left to itself the compiler sinks them to the end
-        // of the iteration and the next one starts with their full latency.
-        float4 a[2][8];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            // a tap outside the image at this position (uniform; 7 % of the tap x position pairs of a 14 x 14 grid)
-            // multiplies zeros: a branch around the MFMAs costs a copy of the 64 accumulators on either path
-            const float von = ((cur.valid >> u) & 1u) ? 1.f : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 f = fold_a_scaled<HAS_T>(rx[u][j], sc[u], sh[u]);
-                const floatx2 lo = floatx2{f.x, f.y} * floatx2{von, von}, hi = floatx2{f.z, f.w} * floatx2{von, von};
-                a[u][j] = make_float4(lo.x, lo.y, hi.x, hi.y);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        issue_x(0, nxt);
-        issue_x(1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            floatx2 lo = {dbs.x, dbs.y}, hi = {dbs.z, dbs.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                lo = __builtin_elementwise_fma(floatx2{rg[j].x, rg[j].y}, floatx2{db_on, db_on}, lo);
-                hi = __builtin_elementwise_fma(floatx2{rg[j].z, rg[j].w}, floatx2{db_on, db_on}, hi);
-            }
-            dbs = make_float4(lo.x, lo.y, hi.x, hi.y);
-        }
-        Frag3 gB[4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) gB[jb] = split_rows(rg, jb, ssel);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_g(nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        Frag3 xa = split_rows(a[0], 0, ssel);
-        // eight stages (tap u, sub-lattice ja): 24 MFMAs each, the next stage's A fragment split in their gaps
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-            const int u = st >> 2, ja = st & 3;
-            Frag3 xn = xa;
-            if (st < 7) xn = split_rows(a[(st + 1) >> 2], (st + 1) & 3, ssel);
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) acc[u][ja * 4 + jb] = mfma16_split6(xa, gB[jb], acc[u][ja * 4 + jb]);
-            if (st < 7) {
-#pragma unroll
-                for (int m = 0; m < 14; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            xa = xn;
-        }
-        cur = nxt;
-    }
-
-    if (HAS_T) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[u][k] *= FOLD_UP;          // exact: the operand was folded times 2^-60
-    }
-    // add the row streams of a tap pair (wave p == 0 keeps the sum): lane-major LDS image of the 128 accumulators
-    float* cb = comb + tp * 8192 + lane;
-    for (int k = 1; k < P; ++k) {
-        if (p == k) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < 64; ++r) cb[(u * 64 + r) * 64] = acc[u][r >> 2][r & 3];
-        }
-        __syncthreads();
-        if (p == 0) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < 64; ++r) acc[u][r >> 2][r & 3] += cb[(u * 64 + r) * 64];
-        }
-        __syncthreads();
-    }
-    if (db_part) {
-        dbs.x += __shfl_xor(dbs.x, 16); dbs.y += __shfl_xor(dbs.y, 16); dbs.z += __shfl_xor(dbs.z, 16); dbs.w += __shfl_xor(dbs.w, 16);
-        dbs.x += __shfl_xor(dbs.x, 32); dbs.y += __shfl_xor(dbs.y, 32); dbs.z += __shfl_xor(dbs.z, 32); dbs.w += __shfl_xor(dbs.w, 32);
-        if (tp == 0 && kq == 0) *reinterpret_cast<float4*>(&comb[p * 64 + 4 * i]) = dbs;
-        __syncthreads();
-        if (tid < 64) {
-            float sum = 0.f;
-            for (int k = 0; k < P; ++k) sum += comb[k * 64 + tid];
-            db_part[(long)bid * 64 + tid] = sum;
-        }
-    }
-    if (p == 0) {
-        float* pb = part + (long)bid * nt_stride * 4096;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (t_u[u] >= nt) continue;
-#pragma unroll
-            for (int ja = 0; ja < 4; ++ja)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ci = 16 * kq + 4 * r + ja;
-                    *reinterpret_cast<float4*>(&pb[t_u[u] * 4096 + ci * 64 + 4 * i]) =
-                        make_float4(acc[u][ja * 4 + 0][r], acc[u][ja * 4 + 1][r], acc[u][ja * 4 + 2][r], acc[u][ja * 4 + 3][r]);
-                }
-        }
-    }
-}
-
 // Four-tap phases {dyA, dyB} x {0, dxr} (the 4 x 4 transposed convs): a wave's two taps sit in ONE operand row, at
 // columns x and x + dxr.  Walking the positions of a grid row against dxr, the rows read for the unshifted tap at one
 // position ARE the shifted tap's rows at the next: they stay in registers as split fragments, so a chunk requests and
-// splits one tap's operand rows instead of two (the operand's rows are the ones that miss, see wgrad_bf3_body; and the
-// split is half of the VALU work).  At the start of a grid row the shifted tap is outside the image (zero fragments);
+// splits one tap's operand rows instead of two (half of the operand requests and of the split's VALU work).  At the start of a grid row the shifted tap is outside the image (zero fragments);
 // where it is not — the first chunk of a stream that starts inside a row — its rows are fetched for that chunk alone.
 template <bool HAS_T>
 __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, const float* __restrict__ A,
@@ -1976,8 +1768,9 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
 }
 
 // the sub-pixel phases of a transposed convolution in one launch (see conv_wgrad_stream_multi_kernel), bf16 pipe
-// ROWS: every phase has four taps in two operand rows (wgrad_bf3_row_body)
-template <bool HAS_T, bool ROWS>
+// the sub-pixel phases of a transposed convolution in one launch (see conv_wgrad_stream_multi_kernel), bf16 pipe; every
+// phase has four taps in two operand rows
+template <bool HAS_T>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_bf3_multi_kernel(ConvGeomMulti p, int nimg, int db_blocks,
                                                                       const float* __restrict__ A,
                                                                       const float* __restrict__ a_scale,
@@ -1990,14 +1783,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_bf3_multi_kernel(ConvGeomMu
     const int ph = (b >= p.begin[1]) + (b >= p.begin[2]) + (b >= p.begin[3]);          // uniform
     const ConvGeom& g = p.g[ph];
     const int b0 = p.begin[ph];
-    if (ROWS)
-        wgrad_bf3_row_body<HAS_T>(g, nimg, A, a_scale, a_shift, G, g_pitch, part + (long)b0 * 4 * 4096,
-                                  (db_part && b < db_blocks) ? db_part + (long)b0 * 64 : nullptr, b - b0,
-                                  p.begin[ph + 1] - b0, comb);
-    else
-        wgrad_bf3_body<HAS_T>(g, 0, g.ntaps, nimg, A, a_scale, a_shift, G, g_pitch, 0, part + (long)b0 * 4 * 4096,
+    wgrad_bf3_row_body<HAS_T>(g, nimg, A, a_scale, a_shift, G, g_pitch, part + (long)b0 * 4 * 4096,
                               (db_part && b < db_blocks) ? db_part + (long)b0 * 64 : nullptr, b - b0,
-                              p.begin[ph + 1] - b0, 4, comb);
+                              p.begin[ph + 1] - b0, comb);
 }
 
 template <bool HAS_T>
@@ -2570,10 +2358,21 @@ extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, c
     }
     // workgroups per geometry in proportion to the time of one of its row streams: chunks / streams per workgroup,
     // a lone tap costing about 0.6 of a pair
-    // large launches whose image count is a multiple of 32: products on the bf16 pipe, one workgroup per CU
+    // large launches of four-tap phases (two operand rows x {unshifted, shifted by one column} in that order, same
+    // operand columns) whose image count is a multiple of 32: products on the bf16 pipe, one workgroup per CU
     long all_rows = 0;
-    for (int k = 0; k < ngeom; ++k) all_rows += p.g[k].rows_total;
-    const bool bf3 = nimg % 32 == 0 && all_rows >= (long)bf3_min_rows();
+    bool rows4 = true;
+    for (int k = 0; k < ngeom; ++k) {
+        const ConvGeom& g = p.g[k];
+        all_rows += g.rows_total;
+        rows4 = rows4 && g.ntaps == 4 && g.sx == 1 && g.Wg == g.Wi;
+        for (int t = 0; rows4 && t < 4; t += 2) {
+            const int d0 = g.dx[t], d1 = g.dx[t + 1];
+            rows4 = g.dy[t] == g.dy[t + 1] && g.a_col[t] == g.a_col[t + 1] &&
+                    ((d0 == 0 && (d1 == 1 || d1 == -1)) || (d1 == 0 && (d0 == 1 || d0 == -1)));
+        }
+    }
+    const bool bf3 = rows4 && nimg % 32 == 0 && all_rows >= (long)bf3_min_rows();
     const int max_blocks = bf3 ? compute_units() : wgrad_grid(1 << 30);
     double wsum = 0., wk[4] = {0., 0., 0., 0.};
     long chunks[4] = {0, 0, 0, 0};
@@ -2602,21 +2401,8 @@ extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, c
     float* db_part = (float*)((char*)workspace + align_up((size_t)wgrad_grid(1 << 30) * 4 * 4096 * sizeof(float)));
     float* dbp = db ? db_part : nullptr;
     if (bf3) {
-        // four taps per phase, as two operand rows x {unshifted, shifted by one column} in that order, same operand
-        // columns: the kernel that keeps the unshifted tap's fragments for the shifted one
-        bool rows4 = true;
-        for (int k = 0; k < ngeom; ++k) {
-            const ConvGeom& g = p.g[k];
-            rows4 = rows4 && g.ntaps == 4 && g.sx == 1 && g.Wg == g.Wi;
-            for (int t = 0; rows4 && t < 4; t += 2) {
-                const int d0 = g.dx[t], d1 = g.dx[t + 1];
-                rows4 = g.dy[t] == g.dy[t + 1] && g.a_col[t] == g.a_col[t + 1] && ((d0 == 0 && (d1 == 1 || d1 == -1)) || (d1 == 0 && (d0 == 1 || d0 == -1)));
-            }
-        }
-#define CMVAE_WG_BF3(HAS_T, ROWS) hipLaunchKernelGGL((conv_wgrad_bf3_multi_kernel<HAS_T, ROWS>), dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp)
-        if (a_scale) { if (rows4) CMVAE_WG_BF3(true, true); else CMVAE_WG_BF3(true, false); }
-        else { if (rows4) CMVAE_WG_BF3(false, true); else CMVAE_WG_BF3(false, false); }
-#undef CMVAE_WG_BF3
+        if (a_scale) hipLaunchKernelGGL(conv_wgrad_bf3_multi_kernel<true>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
+        else hipLaunchKernelGGL(conv_wgrad_bf3_multi_kernel<false>, dim3(used), dim3(256), 0, st, p, nimg, used, A, a_scale, a_shift, G, g_pitch, part, dbp);
         if (int e = check_launch("conv_wgrad_bf3_multi_kernel")) return e;
         hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(4 * 64 + 1, ngeom), dim3(1024), 0, st, part, o, dW, dbp, db, used, 0);
         return check_launch("wgrad_reduce_multi_kernel");

@@ -59,8 +59,8 @@ def test_conv3x3_fwd_dgrad_wgrad(device, n, H, W):
                                           # (1, 2 and 4 taps per phase; fewer chunks than streams; either row order)
                                           (16, 2, 4, False), (32, 4, 3, False), (48, 7, 4, False), (304, 4, 3, True),
                                           (1024, 7, 4, True), (2000, 2, 4, True),
-                                          # >= 196 608 rows with 1 / 2 / 2 / 4 taps per phase (k = 3): the bf16-pipe forward and the
-                                          # general bf16-pipe weight gradient (the 4-tap row-reuse kernel needs k = 4)
+                                          # >= 196 608 rows with 1 / 2 / 2 / 4 taps per phase (k = 3): the bf16-pipe forward next to the
+                                          # fp32 streaming weight gradient (the bf16-pipe one takes four-tap phases: k = 4)
                                           (4128, 4, 3, True)])
 def test_convT_phases_with_bn_fold(device, n, Hi, k, pm):
     """Transposed conv over relu(bn(x)) folded into the operand load; dgrad; wgrad.  pm: pixel-major row order
