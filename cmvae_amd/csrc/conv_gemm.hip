@@ -27,7 +27,9 @@
 #endif
 
 namespace cmvae {
-#if CMVAE_ABLATE == 30      // profiling build: every weight-stationary workgroup logs (start, end) on the 100 MHz wall clock + tiles
+#if CMVAE_ABLATE == 30 || CMVAE_ABLATE == 73 || CMVAE_ABLATE == 74
+// profiling builds: every weight-stationary workgroup logs (start, end) on the 100 MHz wall clock + tiles (30); every
+// wave of the bf16-pipe weight gradient its waits for memory, shader cycles and loop time (73; 74: every load a hit)
 __device__ unsigned long long g_wg_times[3 * 4096];
 __device__ unsigned long long g_wg_quarters[4 * 4096];     // wall clock when the workgroup had done 1/4, 1/2, 3/4, 7/8 of its tiles
 #endif
@@ -1599,7 +1601,7 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
         d.go = live ? op * g_pitch : 0;
         d.sg = live ? img_g : 0;
         d.flags = (row_in ? 1u : 0u) | (sh_in ? 2u : 0u) | (xi == 0 ? 4u : 0u) | (live ? 8u : 0u);
-#if CMVAE_ABLATE == 7      // every load hits the same few rows: the compute-side ceiling of this loop
+#if CMVAE_ABLATE == 7 || CMVAE_ABLATE == 74      // every load hits the same few rows: the compute-side ceiling of this loop
         d.a = d.go = 0; d.sa = d.sg = 0;
 #elif CMVAE_ABLATE == 71   // ... only the operand's loads do
         d.a = 0; d.sa = 0;
@@ -1620,10 +1622,8 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
     float4 rx[8], rg[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);      // (finite, whatever is skipped first)
-    // Rows outside the image (and the prefetch past the end of the range) are NOT requested: a dummy request to one
-    // fixed address from every wave that is at a border row funnels through a single L2 channel — at layer 3 that was
-    // ~110 MB through one channel per launch and a third of the kernel's time (the loads are uniform branches; the
-    // registers' stale contents are multiplied by zero).
+    // Rows outside the image (and the prefetch past the end of the range) are not requested (uniform branches; the
+    // registers' stale, finite contents are multiplied by zero).
     auto issue_x = [&](const Desc& d) {
         if (!(d.flags & 1u)) return;
 #pragma unroll
@@ -1655,7 +1655,7 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
         // position before it in the walk)
         Desc pre = cur;
         pre.a = cur.a + dxr * g.a_pitch;
-#if CMVAE_ABLATE == 7 || CMVAE_ABLATE == 71      // (the ablation builds zero cur.a: stay inside the tensor)
+#if CMVAE_ABLATE == 7 || CMVAE_ABLATE == 71 || CMVAE_ABLATE == 74      // (the ablation builds zero cur.a: stay inside the tensor)
         pre.a = 0;
 #endif
         issue_x(pre);
@@ -1666,8 +1666,22 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
     }
     issue_x(cur);
     issue_g(cur);
+#if CMVAE_ABLATE == 73 || CMVAE_ABLATE == 74     // how long does a wave wait for the rows it requested one chunk earlier (10 ns
+                                                // ticks), and at what shader clock does the loop run?  (74: every load a hit;
+                                                // tools/probe_wgrad_wait.py)
+    unsigned long long wait_total = 0;
+    const unsigned long long loop_t0 = wall_clock64();
+    const long long loop_c0 = clock64();
+#endif
     for (; c < c_end; ++c) {
         const Desc nxt = describe(c + 1, c + 1 < c_end);
+#if CMVAE_ABLATE == 73 || CMVAE_ABLATE == 74
+        {
+            const unsigned long long tw0 = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_total += wall_clock64() - tw0;
+        }
+#endif
         float4 a[8];
         folded(a, (cur.flags & 1u) ? 1.f : 0.f);
         __builtin_amdgcn_sched_barrier(0);
@@ -1722,6 +1736,13 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
         cur = nxt;
     }
 
+#if CMVAE_ABLATE == 73 || CMVAE_ABLATE == 74
+    if (lane == 0 && nchunks > 20000 && bid < 1024) {           // (layer 3 only) per wave: total wait, shader cycles, loop time, chunks
+        unsigned long long* o = g_wg_times + (bid * 4 + w) * 3;
+        o[0] = wait_total; o[1] = (unsigned long long)(clock64() - loop_c0);
+        o[2] = ((wall_clock64() - loop_t0) << 20) | (unsigned long long)(c_end - c_begin);
+    }
+#endif
     if (HAS_T) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -2580,7 +2601,7 @@ extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, con
     return 0;
 }
 
-#if CMVAE_ABLATE == 30
+#if CMVAE_ABLATE == 30 || CMVAE_ABLATE == 73 || CMVAE_ABLATE == 74
 extern "C" int cmvae_debug_wg_times(unsigned long long* out_host, int n_wg) {
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(cmvae::g_wg_times), (size_t)n_wg * 24) == hipSuccess ? 0 : -1;
 }
