@@ -1583,9 +1583,24 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
         sc = scaled4(*reinterpret_cast<const float4*>(a_scale + g.a_col[tn] + 4 * i), FOLD_DOWN);
         sh = scaled4(*reinterpret_cast<const float4*>(a_shift + g.a_col[tn] + 4 * i), FOLD_DOWN);
     }
-    const unsigned lane_a = (unsigned)(8 * kq * img_a + 4 * i) * 4u, lane_g = (unsigned)(8 * kq * img_g + 4 * i) * 4u;
-
-    struct Desc { int a, sa, go, sg; unsigned flags; };          // flags: 1 = row in image, 2 = shifted tap in image,
+    // Requests are buffer loads: the lane's byte offset of each of its eight images is a kernel-wide constant in a
+    // register (voffset), the chunk's offset a scalar (soffset), the tensor a descriptor — no address arithmetic per
+    // request (as global loads each took ~7 scalar instructions or a 64-bit vector add); reads past the tensor's end
+    // would return zero.  (The caller checks that both tensors are smaller than 4 GB.)
+    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (unsigned)((long)nimg * img_a * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, (unsigned)((long)nimg * img_g * 4), 0x00020000);
+    unsigned voff_a[8], voff_g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        voff_a[j] = (unsigned)((8 * kq + j) * img_a + 4 * i) * 4u;
+        voff_g[j] = (unsigned)((8 * kq + j) * img_g + 4 * i) * 4u;
+    }
+    auto load16 = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff_elems) {
+        const uintx4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff_elems * 4, 0);
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    };
+    struct Desc { int a, go; unsigned flags; };                      // flags: 1 = row in image, 2 = shifted tap in image,
                                                                  //        4 = first position of a grid row walk, 8 = live
     auto describe = [&](int c, bool live) {
         Desc d;
@@ -1596,17 +1611,15 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
         const bool row_in = live & ((unsigned)ys < (unsigned)g.Hi) & ((unsigned)xs < (unsigned)g.Wi);
         const bool sh_in = row_in & ((unsigned)(xs + dxr) < (unsigned)g.Wi);
         d.a = row_in ? ((img * g.Hi + ys) * g.Wi + xs) * g.a_pitch + g.a_col[tn] : 0;
-        d.sa = row_in ? img_a : 0;
         const int op = (img * g.Ho + y * g.oys + g.oy0) * g.Wo + x * g.oxs + g.ox0;
         d.go = live ? op * g_pitch : 0;
-        d.sg = live ? img_g : 0;
         d.flags = (row_in ? 1u : 0u) | (sh_in ? 2u : 0u) | (xi == 0 ? 4u : 0u) | (live ? 8u : 0u);
 #if CMVAE_ABLATE == 7 || CMVAE_ABLATE == 74      // every load hits the same few rows: the compute-side ceiling of this loop
-        d.a = d.go = 0; d.sa = d.sg = 0;
+        d.a = d.go = 0;
 #elif CMVAE_ABLATE == 71   // ... only the operand's loads do
-        d.a = 0; d.sa = 0;
+        d.a = 0;
 #elif CMVAE_ABLATE == 72   // ... only the gradient's
-        d.go = 0; d.sg = 0;
+        d.go = 0;
 #endif
         return d;
     };
@@ -1627,14 +1640,12 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
     auto issue_x = [&](const Desc& d) {
         if (!(d.flags & 1u)) return;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            rx[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(A + (d.a + j * d.sa)) + lane_a);
+        for (int j = 0; j < 8; ++j) rx[j] = load16(rsrc_a, voff_a[j], d.a);
     };
     auto issue_g = [&](const Desc& d) {
         if (!(d.flags & 8u)) return;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            rg[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(G + (d.go + j * d.sg)) + lane_g);
+        for (int j = 0; j < 8; ++j) rg[j] = load16(rsrc_g, voff_g[j], d.go);
     };
     auto folded = [&](float4 (&a)[8], float von) {
 #pragma unroll
@@ -2393,7 +2404,10 @@ extern "C" int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, c
                     ((d0 == 0 && (d1 == 1 || d1 == -1)) || (d1 == 0 && (d0 == 1 || d0 == -1)));
         }
     }
-    const bool bf3 = rows4 && nimg % 32 == 0 && all_rows >= (long)bf3_min_rows();
+    // (its requests are buffer loads: 32-bit byte offsets, so both tensors must stay below 4 GB)
+    const bool bf3 = rows4 && nimg % 32 == 0 && all_rows >= (long)bf3_min_rows() &&
+                     (long)nimg * p.g[0].Ho * p.g[0].Wo * g_pitch * 4 < (1L << 32) &&
+                     (long)nimg * p.g[0].Hi * p.g[0].Wi * p.g[0].a_pitch * 4 < (1L << 32);
     const int max_blocks = bf3 ? compute_units() : wgrad_grid(1 << 30);
     double wsum = 0., wk[4] = {0., 0., 0., 0.};
     long chunks[4] = {0, 0, 0, 0};
