@@ -1656,9 +1656,13 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
         }
     };
 
-    Frag3 xprev[4];
+    // A fragments of the unshifted tap: chunk k writes xf[k & 1], the shifted tap of chunk k reads xf[(k & 1) ^ 1] (the
+    // loop is unrolled by two, so nothing is copied from "new" to "previous")
+    Frag3 xf[2][4];
 #pragma unroll
-    for (int ja = 0; ja < 4; ++ja) xprev[ja].p[0] = xprev[ja].p[1] = xprev[ja].p[2] = make_uint4(0u, 0u, 0u, 0u);
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja) xf[q][ja].p[0] = xf[q][ja].p[1] = xf[q][ja].p[2] = make_uint4(0u, 0u, 0u, 0u);
     int c = c_begin;
     Desc cur = describe(c, c < c_end);
     if (c < c_end && (cur.flags & 2u) && !(cur.flags & 4u)) {
@@ -1673,7 +1677,7 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
         float4 a[8];
         folded(a, 1.f);
 #pragma unroll
-        for (int ja = 0; ja < 4; ++ja) xprev[ja] = split_rows(a, ja, ssel);
+        for (int ja = 0; ja < 4; ++ja) xf[1][ja] = split_rows(a, ja, ssel);      // chunk 0 reads xf[1] as "previous"
     }
     issue_x(cur);
     issue_g(cur);
@@ -1684,8 +1688,7 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
     const unsigned long long loop_t0 = wall_clock64();
     const long long loop_c0 = clock64();
 #endif
-    for (; c < c_end; ++c) {
-        const Desc nxt = describe(c + 1, c + 1 < c_end);
+    auto chunk = [&](Frag3 (&xnew)[4], Frag3 (&xprev)[4], const Desc& cur, const Desc& nxt) {
 #if CMVAE_ABLATE == 73 || CMVAE_ABLATE == 74
         {
             const unsigned long long tw0 = wall_clock64();
@@ -1717,7 +1720,6 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
 #pragma unroll
             for (int ja = 0; ja < 4; ++ja) xprev[ja].p[0] = xprev[ja].p[1] = xprev[ja].p[2] = make_uint4(0u, 0u, 0u, 0u);
         }
-        Frag3 xnew[4];
         xnew[0] = split_rows(a, 0, ssel);
         __builtin_amdgcn_sched_barrier(0);
         // stages 0..3: the unshifted tap, the next sub-lattice's fragment split in the gaps of the 24 MFMAs;
@@ -1742,9 +1744,13 @@ __device__ __forceinline__ void wgrad_bf3_row_body(const ConvGeom& g, int nimg, 
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) acc[1][ja * 4 + jb] = mfma16_split6(xprev[ja], gB[jb], acc[1][ja * 4 + jb]);
         }
-#pragma unroll
-        for (int ja = 0; ja < 4; ++ja) xprev[ja] = xnew[ja];
-        cur = nxt;
+    };
+    for (; c < c_end; c += 2) {
+        const Desc nxt = describe(c + 1, c + 1 < c_end);
+        chunk(xf[0], xf[1], cur, nxt);
+        if (c + 1 >= c_end) break;                               // uniform
+        cur = describe(c + 2, c + 2 < c_end);
+        chunk(xf[1], xf[0], nxt, cur);
     }
 
 #if CMVAE_ABLATE == 73 || CMVAE_ABLATE == 74
