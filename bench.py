@@ -237,6 +237,8 @@ def roofline_conv_gemm(step_fn):
     names = ('conv_gemm', 'conv_gemm_multi', 'conv_gemm_bnbwd', 'conv_wgrad_multi')
     origs = {n: getattr(conv, n) for n in names}
 
+    pipe = lambda kind, gs: 'bf16' if conv.on_bf16_pipe(kind, gs) else 'f32'      # noqa: E731
+
     def timed(name, flops_of, group_of):
         orig = origs[name]
 
@@ -250,14 +252,14 @@ def roofline_conv_gemm(step_fn):
             if grp:
                 # kernel launches behind the call: a data gradient on the bf16 pipe runs as accumulating passes of at
                 # most six taps (rocprof counts those)
-                nk = -(-args[0].ntaps // 6) if (name == 'conv_gemm_bnbwd' and grp == 'bf16') else 1
+                nk = -(-args[0].ntaps // 6) if (name in ('conv_gemm_bnbwd', 'conv_gemm') and grp == 'bf16') else 1
                 rec[grp].append((e0, e1, flops_of(*args, **kw), nk))
             return r
         return f
 
-    pipe = lambda kind, gs: 'bf16' if conv.on_bf16_pipe(kind, gs) else 'f32'      # noqa: E731
     conv.conv_gemm = timed('conv_gemm', lambda g, *a, **kw: useful_flops(g, kw.get('n_col_blocks', 1)),
-                           lambda g, *a, **kw: 'f32')
+                           lambda g, *a, **kw: pipe('gemm', [g]) if (kw.get('n_col_blocks', 1) == 1 and
+                                                                     kw.get('act', 0) == 0) else 'f32')
     conv.conv_gemm_multi = timed('conv_gemm_multi', lambda gs, *a, **kw: sum(useful_flops(g, 1) for g in gs),
                                  lambda gs, *a, **kw: pipe('multi', gs))
     conv.conv_gemm_bnbwd = timed('conv_gemm_bnbwd', lambda g, *a, **kw: useful_flops(g, 1),
@@ -291,7 +293,8 @@ def roofline_conv_gemm(step_fn):
         return d
 
     bf = group('bf16', 'conv_gemm_wstat(_multi)_kernel<.., BF3> + conv_wgrad_bf3_multi_kernel (decoder layers 2-3: forward, '
-               'data gradient, weight gradient; fp32 products as six bf16 MFMA products)', _is_bf16_pipe,
+               'data gradient, weight gradient; encoder 3x3 conv at 14x14: forward, data gradient; fp32 products as six '
+               'bf16 MFMA products)', _is_bf16_pipe,
                BF16_PIPE_F32_EQUIV_PEAK_TFLOPS,
                lambda a: {'achieved_unit_note': 'algorithmic (fp32) FLOP/s', 'peak_note': 'bf16 dense MFMA peak 2500 / 6 '
                           'products per fp32 product', 'frac_of_fp32_mfma_peak': round(a / MFMA_F32_PEAK_TFLOPS, 4)})

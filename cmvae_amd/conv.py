@@ -149,12 +149,15 @@ def bf16_pipe_min_rows():
 def on_bf16_pipe(kind, geoms):
     """Whether a launch runs its fp32 products on the bf16 matrix pipe (three-piece split, six products) — the rules
     of csrc/conv_gemm.hip restated for measurement code (bench.py groups its roofline by pipe) and tests.
-    kind: 'multi' (conv_gemm_multi), 'bnbwd' (conv_gemm_bnbwd), 'wgrad_multi' (conv_wgrad_multi: four-tap phases)."""
+    kind: 'gemm' (conv_gemm with act = 0 and one column block), 'multi' (conv_gemm_multi), 'bnbwd' (conv_gemm_bnbwd),
+    'wgrad_multi' (conv_wgrad_multi: four-tap phases)."""
     gs = list(geoms)
     g0 = gs[0]
     npix = g0.Hg * g0.Wg
     pm = bool(g0.pixel_major) and npix > 0 and g0.rows_total // npix >= 64
     rows = sum(g.rows_total for g in gs)
+    if kind == 'gemm':          # conv_gemm (act 0, one column block): 7 .. 9 taps in two passes, either row order
+        return 6 < g0.ntaps <= 9 and rows >= bf16_pipe_min_rows()
     if kind == 'multi':
         return pm and rows >= bf16_pipe_min_rows()
     if kind == 'bnbwd':

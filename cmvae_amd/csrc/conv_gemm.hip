@@ -340,6 +340,12 @@ __device__ __forceinline__ floatx16 mfma_split6(const Frag3& a, const Frag3& b, 
 // fit 160 KB: 147 456 bytes).
 constexpr int BF3_TAP_BYTES = 3 * 64 * 128;
 constexpr int BF3_TAPS = 6;                              // taps whose planes fit LDS at once
+// rows from which a pixel-major weight-stationary launch runs its products on the bf16 pipe (BF3): from about three
+// 256-row tiles per CU on, as for the 8-wave fp32 kernel
+#ifndef CMVAE_BF3_MIN_ROWS
+#define CMVAE_BF3_MIN_ROWS (3 * 256 * 256)     // (a comparison build sets it out of reach: tools/ab_bench.sh)
+#endif
+static int bf3_min_rows() { return CMVAE_BF3_MIN_ROWS; }
 __device__ __forceinline__ int bf3_elem(int pl, int co, int chunk) {         // element (bf16) index within a tap
     return ((pl * 64 + co) * 8 + (chunk ^ ((co >> 1) & 7))) * 8;
 }
@@ -1158,9 +1164,22 @@ static int dispatch_wstat(const ConvGeom& g, const float* A, const float* Wt, co
     // evaluation's second encoder layer, 78400 rows = 306 tiles, ran 125 us here against the direct kernel's 128-row
     // tiles on three workgroups per CU)
     // (a launch of at most one 256-row tile per CU — a single round again — was measured too: no gain, 13.07 vs 13.07 ms)
-    if (g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256)
+    if (g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256) {
+        // 7 .. 9 taps (the encoder's 3 x 3 convs and their data gradients) on the bf16 pipe (mfma_split6): two passes of at
+        // most six taps of weight planes, the second adding to the first one's output and carrying the bias and the
+        // statistics.  Same-box A/B of the Omniglot 20-way step: 11.41 / 11.33 -> 11.27 / 11.21 ms (the output is 64 MB
+        // there; layer 2's 9-tap data gradient, whose output is 481 MB, loses by the read-modify-write and stays on the
+        // fp32 MFMA: cmvae_conv_gemm_bnbwd).
+        if (ACT == 0 && n_col_blocks == 1 && g.ntaps > BF3_TAPS && g.rows_total >= bf3_min_rows()) {
+            const int t1 = (g.ntaps + 1) / 2;
+            if (int e = launch_wstat<0, HAS_T, 8, PM, false, false, true>(g, A, Wt, nullptr, a_scale, a_shift, out, nullptr, 0,
+                                                                          1, 0, t1, st)) return e;
+            return launch_wstat<0, HAS_T, 8, PM, false, true, true>(g, A, Wt, bias, a_scale, a_shift, out, stats_part,
+                                                                    stats_rows, 1, t1, g.ntaps - t1, st);
+        }
         return launch_wstat<ACT, HAS_T, 8, PM>(g, A, Wt, bias, a_scale, a_shift, out, stats_part, stats_rows,
                                                n_col_blocks, 0, g.ntaps, st);
+    }
     *handled = false;
     return 0;
 }
@@ -2007,12 +2026,6 @@ static ConvGeom to_geom(const cmvae_conv_geom* c) {
     return g;
 }
 
-// rows from which a pixel-major weight-stationary launch runs its products on the bf16 pipe (BF3): from about three
-// 256-row tiles per CU on, as for the 8-wave fp32 kernel
-#ifndef CMVAE_BF3_MIN_ROWS
-#define CMVAE_BF3_MIN_ROWS (3 * 256 * 256)     // (a comparison build sets it out of reach: tools/ab_bench.sh)
-#endif
-static int bf3_min_rows() { return CMVAE_BF3_MIN_ROWS; }
 
 static int gemm_grid(int rows_total, int nblk_cols) {
     const int ntiles = (rows_total + BM - 1) / BM;

@@ -19,7 +19,9 @@ def from_nhwc(m, n, H, W):
     return m.view(n, H, W, -1).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize('n,H,W', [(3, 7, 7), (5, 14, 14), (2, 4, 4), (130, 2, 2), (16, 7, 7), (48, 5, 3), (160, 2, 2)])
+@pytest.mark.parametrize('n,H,W', [(3, 7, 7), (5, 14, 14), (2, 4, 4), (130, 2, 2), (16, 7, 7), (48, 5, 3), (160, 2, 2),
+                                   # >= 196 608 rows: forward and data gradient as two passes (5 + 4 taps) on the bf16 pipe
+                                   (1040, 14, 14)])
 def test_conv3x3_fwd_dgrad_wgrad(device, n, H, W):
     from cmvae_amd import conv
     g = torch.Generator().manual_seed(n)
