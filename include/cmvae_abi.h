@@ -215,8 +215,9 @@ int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A, const flo
  * 64-column block, all in the same row order.  stats_part (or NULL): [cmvae_conv_gemm_multi_grid()][128] partial
  * column sums {sum, sum of squares} over ALL geometries' rows.                                                  */
 int cmvae_conv_gemm_multi_grid(void);
-/* Rows from which the pixel-major launches of cmvae_conv_gemm_multi, cmvae_conv_gemm_bnbwd (<= 6 or 10 .. 18 taps)
- * and cmvae_conv_wgrad_multi (image count a multiple of 32) run their fp32 products on the bf16 matrix pipe: every
+/* Rows from which cmvae_conv_gemm (7 .. 9 taps, act 0, one column block), the pixel-major launches of
+ * cmvae_conv_gemm_multi and cmvae_conv_gemm_bnbwd (<= 6 or 10 .. 18 taps) and cmvae_conv_wgrad_multi (four-tap phases,
+ * image count a multiple of 32) run their fp32 products on the bf16 matrix pipe: every
  * operand split exactly into three bf16 pieces, six v_mfma_*_bf16 products per fp32 product, fp32 accumulation — the
  * results are fp32 results (tests/test_gpu_conv.py: test_bf16_pipe_products_are_fp32_products).  No counterpart in the
  * reference (omniglot/module.py:50-58 calls torch's conv_transpose2d); a measurement aid for bench.py and tests.  */
