@@ -9,16 +9,18 @@
 // where r enumerates (image, y, x) over a per-image grid, src(r,t) = (image, y*sy+dy_t,
 // x*sx+dx_t) (zero outside the image) and T is an optional per-channel affine + ReLU (the
 // previous layer's BatchNorm folded into the operand load).  v_mfma_f32_32x32x2_f32 does the
-// math (exact fp32 fma chains).  Kernels, by where the operands live:
+// math (exact fp32 fma chains); the big launches (BF3 instantiations, conv_wgrad_bf3_multi_kernel) run the same fp32
+// products as six bf16 MFMA products of exact three-piece operand splits (mfma_split6).  Kernels, by where the operands live:
 //   conv_gemm_kernel               A and W_t tiles staged through LDS with register prefetch (folded launches > 9 taps)
 //   conv_gemm_direct_kernel        A fragments straight from global memory, W_t tile through LDS per tap (2 barriers)
 //   conv_gemm_wstat_kernel         all W_t of the launch resident in LDS, A from global memory, no barrier (<= 9 taps;
 //                                  _multi_: up to four geometries side by side = the phases of a transposed conv;
-//                                  ACCUM: second half of a 16-tap data gradient; BNB: BatchNorm-backward sums epilogue)
+//                                  ACCUM: a later pass over another tap range, adding to the output; BNB:
+//                                  BatchNorm-backward sums epilogue; BF3: products on the bf16 pipe, <= 6 taps)
 // The weight-gradient kernels contract over r instead (conv_wgrad_stream_kernel: fragments straight from global
-// memory on v_mfma_f32_16x16x4_f32; conv_wgrad_kernel: LDS-staged, any shape).
+// memory on v_mfma_f32_16x16x4_f32; conv_wgrad_bf3_multi_kernel: the same on the bf16 pipe for four-tap phases;
+// conv_wgrad_kernel: LDS-staged, any shape).
 #include "common.h"
-#include <utility>
 #ifndef CMVAE_ABLATE
 #define CMVAE_ABLATE 0
 #endif
