@@ -344,6 +344,9 @@ constexpr int BF3_TAP_BYTES = 3 * 64 * 128;
 constexpr int BF3_TAPS = 6;                              // taps whose planes fit LDS at once
 // rows from which a pixel-major weight-stationary launch runs its products on the bf16 pipe (BF3): from about three
 // 256-row tiles per CU on, as for the 8-wave fp32 kernel
+#ifndef CMVAE_BF3_LINEAR
+#define CMVAE_BF3_LINEAR 16384     // rows from which nn.Linear launches take the bf16 pipe (0: never; see launch_gemm)
+#endif
 #ifndef CMVAE_BF3_MIN_ROWS
 #define CMVAE_BF3_MIN_ROWS (3 * 256 * 256)     // (a comparison build sets it out of reach: tools/ab_bench.sh)
 #endif
@@ -2488,6 +2491,21 @@ static ConvGeom linear_geom(int rows, int K, int N, int a_pitch, int o_pitch) {
 static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const float* bias, int act, int ncb,
                        float* out, hipStream_t st, const float* mse_target = nullptr, int mse_M = 1, int mse_pitch = 0,
                        float* mse_part = nullptr) {
+#if CMVAE_BF3_LINEAR
+    // in_features 64 .. 384 over many rows (proj, the (mu, logvar) head, causal fc1 and their data gradients at the
+    // per-sample row counts): the column block's weight planes resident in LDS (weight-stationary kernel, 8 waves),
+    // products on the bf16 pipe.  Same-box A/B: Omniglot 20-way step 11.33 -> 11.18 ms (64-input fc1 included: -0.04 more),
+    // Mini-ImageNet step 1.451 -> 1.418 ms.
+    if (!mse_target && g.ntaps <= BF3_TAPS && g.rows_total >= CMVAE_BF3_LINEAR && (g.ntaps >= 2 || ncb >= 8)) {
+        const float* none = nullptr;
+        switch (act) {
+            case 0: return launch_wstat<0, false, 8, false, false, false, true>(g, A, Wt, bias, none, none, out, nullptr, 0, ncb, 0, g.ntaps, st);
+            case 1: return launch_wstat<1, false, 8, false, false, false, true>(g, A, Wt, bias, none, none, out, nullptr, 0, ncb, 0, g.ntaps, st);
+            default: return launch_wstat<2, false, 8, false, false, false, true>(g, A, Wt, bias, none, none, out, nullptr, 0, ncb, 0, g.ntaps, st);
+        }
+    }
+#endif
+    // (fp32 MFMA, below the bf16 pipe's row count:)
     // in_features = 64 into many column blocks over many rows (fc1 of the NOTEARS-MLP layer, 64 -> 2048): a step of the
     // direct kernel would be one 64-deep tap between two barriers; here a workgroup keeps its column block's weight
     // tile in LDS and walks the row tiles without a barrier (147 vs 176 us on [38400, 64]).  Measured slower or equal

@@ -20,7 +20,10 @@ ACTS = {None: lambda v: v, 'relu': F.relu, 'elu': F.elu}
     (300, 128, 256, 'elu'), (1000, 256, 256, 'relu'), (77, 64, 2048, 'elu'), (513, 2048, 64, None),
     (1, 256, 128, None), (1200, 512, 512, 'relu'), (129, 64, 64, None),
     # 64 -> many column blocks over >= 8192 rows: the weight-stationary kernel (ragged last row tile)
-    (8200, 64, 512, 'elu'), (9001, 64, 1024, None)])
+    (8200, 64, 512, 'elu'), (9001, 64, 1024, None),
+    # >= 16 384 rows with in_features <= 384 (and the data gradient where out_features <= 384): weight planes resident
+    # in LDS, products on the bf16 pipe (ragged last row tile; 1, 2, 4 and 6 taps)
+    (20001, 256, 256, 'elu'), (16400, 64, 2048, 'relu'), (17000, 384, 128, None), (20000, 128, 64, None)])
 def test_linear_fwd_bwd(rows, in_f, out_f, act):
     from cmvae_amd.linear import linear
     g = torch.Generator().manual_seed(rows + in_f)
