@@ -243,13 +243,32 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
 // y3 [n,14,14,64] --relu(bn3)--> convT(64->1,k4,s2,p1) + b --sigmoid--> p [n,28,28];
 // loss_part[img] = -sum_pix ( x*max(log p,-100) + (1-x)*max(log1p(-p),-100) ),  x = target[img / M]
 //
-// Per image: Y[pix][tap] = a3[pix][0:64] . w4[0:64][tap] on v_mfma_f32_16x16x4_f32 (16 pixels x 16 taps per
-// accumulator, 13 row blocks per image, operand fragments straight from global memory), then every output pixel
-// gathers its <= 4 (pixel, tap) terms from LDS.  One block barrier per image (Y is double-buffered).
+// Per image: Y[tap][pix] = w4^T[tap][0:64] . a3^T[0:64][pix] on v_mfma_f32_16x16x4_f32 (16 taps x 16 pixels per
+// accumulator, 13 blocks of 16 pixels per image, operand fragments straight from global memory); a lane then holds
+// the four kx taps of one (pixel, ky) and stores them as 16 bytes into the pixel's slot of a zero-bordered 16 x 16
+// grid in LDS, from which every output pixel reads its four (pixel, tap) terms at constant offsets -- no bounds
+// tests, no index arithmetic per image.  One block barrier per image (Y is double-buffered).
+// The kernel is bound by its instruction count (with every load an L2 hit it is 15 % faster, without the MFMAs'
+// 130 us it would still take 300): everything that does not depend on the image is computed once.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int HI = 14, HO = 28, NPIX_I = HI * HI, NPIX_O = HO * HO;
 constexpr int RB = (NPIX_I + 15) / 16;  // 13 blocks of 16 pixels (12 padded rows)
-constexpr int YP = 20;                 // pitch of Y: 4*YP = 16 (mod 64) makes the accumulator stores conflict-free
+constexpr int YP = 20;                 // floats per pixel slot: 16-byte stores and the gather's reads conflict-free
+constexpr int YSLOTS = 256;            // slot of input pixel (iy, ix) = (iy + 1) * 16 + ix + 1; the border stays zero
+
+// sum over the wave's 64 lanes, the same value on every lane's row leader path: four rotations within the rows of 16
+// lanes (DPP, no LDS round trips), then the four row sums through scalar registers
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define CMVAE_ROR_ADD(n) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + n, 0xf, 0xf, false))
+    CMVAE_ROR_ADD(8); CMVAE_ROR_ADD(4); CMVAE_ROR_ADD(2); CMVAE_ROR_ADD(1);
+#undef CMVAE_ROR_ADD
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 
 __global__ __launch_bounds__(256, 3) void dec_out_fwd_kernel(const float* __restrict__ y3,
                                                              const float* __restrict__ scale,
@@ -258,28 +277,51 @@ __global__ __launch_bounds__(256, 3) void dec_out_fwd_kernel(const float* __rest
                                                              const float* __restrict__ b4,
                                                              const float* __restrict__ target, int M, int nimg,
                                                              float* __restrict__ p_out, float* __restrict__ loss_part) {
-    __shared__ float ys[2][RB * 16 * YP];            // double-buffered: one block barrier per image
+    __shared__ __align__(16) float ys[2][YSLOTS * YP];      // double-buffered: one block barrier per image
     __shared__ float lred[2][4];
+    __shared__ __align__(16) float fold[2][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    // MFMA (t, j) contracts channel 16t + 4g + j on lane group g: the A operand of a 16-pixel block is one float4 per
-    // t straight from the pixel's global row (64 contiguous bytes per pixel and t over the four lane groups) -- the
-    // activations never pass through LDS; BatchNorm + ReLU are applied on the registers.
+    // MFMA (t, j) contracts channel 16t + 4g + j on lane group g: the pixel operand of a 16-pixel block is one float4
+    // per t straight from the pixel's global row (64 contiguous bytes per pixel and t over the four lane groups) -- the
+    // activations never pass through LDS; BatchNorm + ReLU are applied on the registers with the clamped
+    // one-instruction fold of conv_gemm.hip (relu(bn(y)) * 2^-60 against w4 * 2^60: same bits).
     float bw[16];
-    float4 sc[4], sh[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bw[4 * t + j] = w4[(16 * t + 4 * g + j) * 16 + i];
-        sc[t] = *reinterpret_cast<const float4*>(scale + 16 * t + 4 * g);
-        sh[t] = *reinterpret_cast<const float4*>(shift + 16 * t + 4 * g);
+        for (int j = 0; j < 4; ++j) bw[4 * t + j] = w4[(16 * t + 4 * g + j) * 16 + i] * 0x1p60f;
+    // the fold constants of the lane's 16 channels would be 32 registers (the kernel runs three workgroups per CU on
+    // 168): they are read from LDS per image instead, 8 x 16 bytes
+    if (tid < 64) {
+        fold[0][tid] = scale[tid] * 0x1p-60f;
+        fold[1][tid] = shift[tid] * 0x1p-60f;
     }
     const float bias = b4[0];
-    // row blocks w, w+4, w+8 (and 12 on wave 0), one image ahead in registers (two images ahead at two workgroups
-    // per CU was measured: 518 vs 485 us -- the kernel is not waiting for its loads)
-    const int nb = w == 0 ? 4 : 3;                   // uniform per wave
+    for (int e = tid; e < 2 * YSLOTS * YP; e += 256) (&ys[0][0])[e] = 0.f;
+    // where the lane's accumulators go: pixel 16 blk + i, taps 4g .. 4g+3 (float index into a Y buffer)
+    int sidx[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int px = 16 * (b < 3 ? w + 4 * b : 12) + i;
+        sidx[b] = (px + 2 * (px / HI) + 17) * YP + 4 * g;
+    }
+    const bool tail_ok = i < NPIX_I - 16 * 12;       // the 13th block holds 4 pixels; its other rows are never stored
+    // what output pixel o = tid + 256 k reads: input pixels (iy0 - a, ix0 - b) with taps (ky0 + 2a, kx0 + 2b);
+    // gidx = slot(iy0 - 1, ix0 - 1) * YP + 4 ky0 + kx0, the four terms at + {17 YP, 16 YP + 2, YP + 8, 10}
+    int gidx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = tid + 256 * k < NPIX_O ? tid + 256 * k : 0;
+        const int oy = o / HO, ox = o - oy * HO;
+        gidx[k] = (((oy + 1) >> 1) * 16 + ((ox + 1) >> 1)) * YP + ((oy + 1) & 1) * 4 + ((ox + 1) & 1);
+    }
+    // row blocks w, w+4, w+8 of every image and the 13th block on wave (image count & 3): a fixed owner would be the
+    // slowest wave of every image, and the first waves of the resident workgroups share a SIMD.  One image ahead in
+    // registers (two images ahead at two workgroups per CU was measured: 518 vs 485 us -- the kernel is not waiting
+    // for its loads)
     float4 pre[4][4];
-    auto fetch = [&](int img) {
+    auto fetch = [&](int img, int nbf) {
 #if defined(CMVAE_DEC_ABL) && CMVAE_DEC_ABL == 3      // timing only: the activations come from 32 images (L2 hits)
         const float* yi = y3 + (long)(img & 31) * NPIX_I * C + 4 * g;
 #else
@@ -287,92 +329,87 @@ __global__ __launch_bounds__(256, 3) void dec_out_fwd_kernel(const float* __rest
 #endif
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            if (b < nb) {
-                const int px = 16 * (w + 4 * b) + i;
+            if (b < nbf) {
+                const int px = 16 * (b < 3 ? w + 4 * b : 12) + i;
                 const float* pr = yi + (px < NPIX_I ? px : NPIX_I - 1) * C;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) pre[b][t] = *reinterpret_cast<const float4*>(pr + 16 * t);
             }
         }
     };
-    if ((int)blockIdx.x < nimg) fetch(blockIdx.x);
-    int buf = 0;
-    for (int img = blockIdx.x; img < nimg; img += gridDim.x, buf ^= 1) {
+    auto blocks_of = [&](int it) { return w == (it & 3) ? 4 : 3; };       // uniform per wave
+    if ((int)blockIdx.x < nimg) fetch(blockIdx.x, blocks_of(0));
+    __syncthreads();              // the borders are zero before any wave stores a pixel
+    int buf = 0, it = 0;
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x, buf ^= 1, ++it) {
+        const int nb = blocks_of(it);
         float* yb = ys[buf];
         typedef float floatx2 __attribute__((ext_vector_type(2)));
         floatx4 acc[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[b] = floatx4{0.f, 0.f, 0.f, 0.f};
+        int fo = 4 * g;
+        asm volatile("" : "+v"(fo));      // per image: keeps the compiler from holding all 32 constants in registers
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float4 a[4];
+            const float4 sct = *reinterpret_cast<const float4*>(&fold[0][16 * t + fo]);
+            const float4 sht = *reinterpret_cast<const float4*>(&fold[1][16 * t + fo]);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 if (b < nb) {
+                    // both halves and the two wait states a v_mfma needs behind a VALU write in one block (the hazard
+                    // recognizer does not look into inline asm)
                     const float4 v = pre[b][t];
-                    const floatx2 lo = __builtin_elementwise_fma(floatx2{v.x, v.y}, floatx2{sc[t].x, sc[t].y}, floatx2{sh[t].x, sh[t].y});
-                    const floatx2 hi = __builtin_elementwise_fma(floatx2{v.z, v.w}, floatx2{sc[t].z, sc[t].w}, floatx2{sh[t].z, sh[t].w});
-                    const bool ok = 16 * (w + 4 * b) + i < NPIX_I;          // padded rows of the 13th block contribute zero
-                    a[b].x = ok ? fmaxf(lo.x, 0.f) : 0.f; a[b].y = ok ? fmaxf(lo.y, 0.f) : 0.f;
-                    a[b].z = ok ? fmaxf(hi.x, 0.f) : 0.f; a[b].w = ok ? fmaxf(hi.y, 0.f) : 0.f;
+                    floatx2 lo, hi;
+                    asm("v_pk_fma_f32 %0, %2, %3, %4 clamp\n\tv_pk_fma_f32 %1, %5, %6, %7 clamp\n\ts_nop 1"
+                        : "=&v"(lo), "=v"(hi)
+                        : "v"(floatx2{v.x, v.y}), "v"(floatx2{sct.x, sct.y}), "v"(floatx2{sht.x, sht.y}),
+                          "v"(floatx2{v.z, v.w}), "v"(floatx2{sct.z, sct.w}), "v"(floatx2{sht.z, sht.w}));
+                    a[b] = make_float4(lo.x, lo.y, hi.x, hi.y);
                 }
             }
             // independent accumulator chains interleaved, so a dependent MFMA never waits for its own chain
 #pragma unroll
-            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].x, bw[4 * t + 0], acc[b], 0, 0, 0);
+            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[4 * t + 0], a[b].x, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].y, bw[4 * t + 1], acc[b], 0, 0, 0);
+            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[4 * t + 1], a[b].y, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].z, bw[4 * t + 2], acc[b], 0, 0, 0);
+            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[4 * t + 2], a[b].z, acc[b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].w, bw[4 * t + 3], acc[b], 0, 0, 0);
+            for (int b = 0; b < 4; ++b) if (b < nb) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[4 * t + 3], a[b].w, acc[b], 0, 0, 0);
         }
-        if (img + (int)gridDim.x < nimg) fetch(img + gridDim.x);
+        if (img + (int)gridDim.x < nimg) fetch(img + gridDim.x, blocks_of(it + 1));
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (b < nb) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) yb[(16 * (w + 4 * b) + 4 * g + reg) * YP + i] = acc[b][reg];   // row 4g+reg, tap i
-            }
+        for (int b = 0; b < 3; ++b) *reinterpret_cast<floatx4*>(&yb[sidx[b]]) = acc[b];      // taps (ky = g, kx = 0..3)
+        if (nb == 4 && tail_ok) *reinterpret_cast<floatx4*>(&yb[sidx[3]]) = acc[3];
         __syncthreads();          // the image's Y is complete; the other buffer is free for the next image
-        const float* tg = target + (long)(img / M) * NPIX_O;
+        const float* tg = target + (long)(img / M) * NPIX_O + tid;
+        float* po = p_out + (long)img * NPIX_O + tid;
         float lsum = 0.f;
-#if defined(CMVAE_DEC_ABL) && CMVAE_DEC_ABL == 2      // timing only: no gather phase at all
-        for (int o = tid; o < 256; o += 256) {
-#else
-        for (int o = tid; o < NPIX_O; o += 256) {
-#endif
-            const int oy = o / HO, ox = o - oy * HO;
-            // output row oy takes kernel row ky = oy + 1 - 2*iy from input row iy: two candidates
-            const int iy0 = (oy + 1) >> 1, ky0 = oy + 1 - 2 * iy0;
-            const int ix0 = (ox + 1) >> 1, kx0 = ox + 1 - 2 * ix0;
-            float acc1 = bias;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int iy = iy0 - a, ky = ky0 + 2 * a;
-                if (iy < 0 || iy >= HI) continue;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int ix = ix0 - b, kx = kx0 + 2 * b;
-                    if (ix < 0 || ix >= HI) continue;
-                    acc1 += yb[(iy * HI + ix) * YP + ky * 4 + kx];
-                }
-            }
-            // hardware exp / log / rcp (1 ulp-class): the loss is a sum of 784 O(1) terms per image, the tolerance
+        for (int k = 0; k < 4; ++k) {
+            if (k == 3 && tid >= NPIX_O - 3 * 256) break;
+            const float* yq = yb + gidx[k];
+            // same order of the four terms as always: (iy0, ix0), (iy0, ix0 - 1), (iy0 - 1, ix0), (iy0 - 1, ix0 - 1)
+            float acc1 = bias + yq[17 * YP];
+            acc1 += yq[16 * YP + 2];
+            acc1 += yq[YP + 8];
+            acc1 += yq[10];
+            // hardware exp / log (1 ulp-class): the loss is a sum of 784 O(1) terms per image, the tolerance
             // 1e-4 relative; log(1-p) from the rounded p like BCELoss does (saturates to the -100 clamp)
 #if defined(CMVAE_DEC_ABL) && CMVAE_DEC_ABL == 1      // timing only: no transcendentals
             const float p = acc1;
-            p_out[(long)img * NPIX_O + o] = p;
-            lsum -= tg[o] * p;
+            po[256 * k] = p;
+            lsum -= tg[256 * k] * p;
 #else
             const float p = __frcp_rn(1.f + __expf(-acc1));
-            p_out[(long)img * NPIX_O + o] = p;
-            const float x = tg[o];
+            po[256 * k] = p;
+            const float x = tg[256 * k];
             lsum -= x * fmaxf(__logf(p), -100.f) + (1.f - x) * fmaxf(__logf(1.f - p), -100.f);
 #endif
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+        lsum = wave_sum_dpp(lsum);
         if (lane == 0) lred[buf][w] = lsum;
         // the wave that finishes last cannot be known without a barrier: the sum of the four is written one image
         // later, after the next image's barrier (and once more after the loop)
