@@ -686,6 +686,23 @@ __global__ __launch_bounds__(256, 3) void dec_out_bwd_lin_kernel(const float* __
     float* xw = xst[w];
     float* mw = mst[w];
     constexpr int NPT = (NPIX_O + 255) / 256;
+    // nothing below depends on the image: where the thread's dlogit values go, and where the contraction's D operand
+    // (pixel 16 blk + 4 s4 + g, tap i) is read from; pixels past the image read the zero border (dl[0])
+    int didx[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int o = tid + 256 * k, oy = o / HO;
+        didx[k] = (oy + 1) * PL + (o - oy * HO) + 1;
+    }
+    int bidx[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int px = 16 * (q < 3 ? w + 4 * q : 12) + 4 * s4 + g;
+            const int iy = px / HI, ix = px - iy * HI;
+            bidx[q][s4] = px < NPIX_I ? (2 * iy + (i >> 2)) * PL + 2 * ix + (i & 3) : 0;      // tap i = ky*4 + kx
+        }
     float pp[NPT], tt[NPT];
     float4 vv[4];
     auto fetch_pt = [&](int img) {
@@ -697,66 +714,70 @@ __global__ __launch_bounds__(256, 3) void dec_out_bwd_lin_kernel(const float* __
             tt[k] = tg[oo];
         }
     };
-    auto fetch_rows = [&](int img, int rbk) {
+    // rows g + 4j of pixel block q (blocks w, w+4, w+8 and the 13th); the 13th block has four pixels: its rows 4 .. 15
+    // are copies of them, multiplied by the zero border in the contraction
+    auto fetch_rows = [&](int img, int q) {
 #if defined(CMVAE_DEC_ABL) && CMVAE_DEC_ABL == 3      // timing only: the activations come from 32 images (L2 hits)
         const float* yi = y3 + (long)(img & 31) * NPIX_I * C;
 #else
         const float* yi = y3 + (long)img * NPIX_I * C;
 #endif
+        if (q < 3) {
+            const float* pr = yi + (16 * (w + 4 * q) + g) * C + 4 * i;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int px = 16 * rbk + g + 4 * j;
-            vv[j] = *reinterpret_cast<const float4*>(yi + (px < NPIX_I ? px : NPIX_I - 1) * C + 4 * i);
+            for (int j = 0; j < 4; ++j) vv[j] = *reinterpret_cast<const float4*>(pr + 4 * j * C);
+        } else {
+            vv[0] = *reinterpret_cast<const float4*>(yi + (16 * 12 + g) * C + 4 * i);
+            vv[1] = vv[0]; vv[2] = vv[0]; vv[3] = vv[0];
         }
     };
     if ((int)blockIdx.x < nimg) {
         fetch_pt(blockIdx.x);
-        fetch_rows(blockIdx.x, w);
+        fetch_rows(blockIdx.x, 0);
     }
-    for (int img = blockIdx.x; img < nimg; img += gridDim.x, buf ^= 1) {
+    int it = 0;
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x, buf ^= 1, ++it) {
         float* dlb = dl[buf];
         const bool more = img + (int)gridDim.x < nimg;
+        // the 13th block goes round the waves: a fixed owner would be the slowest wave of every image
+        const bool has13 = w == (it & 3);
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
-            const int o = tid + 256 * k;
             const float p = pp[k], x = tt[k];
             const float pq = p * (1.f - p);
             const float d = gscale * (p - x) * (pq >= 1e-12f ? 1.f : pq * 1e12f);     // as dec_out_bwd_kernel
-            const int oy = o / HO;
-            if (o < NPIX_O) {
-                dlb[(oy + 1) * PL + (o - oy * HO) + 1] = d;
+            if (tid + 256 * k < NPIX_O) {
+                dlb[didx[k]] = d;
                 dbs += d;
             }
         }
         if (more) fetch_pt(img + gridDim.x);
         __syncthreads();          // the only block barrier per image (dl is double-buffered)
-        for (int rbk = w; rbk < RB; rbk += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q == 3 && !has13) break;
             // ---- rows: m * xhat and m, staged for the contraction over the pixels
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int rr = g + 4 * j, px = 16 * rbk + rr;
-                const bool ok = px < NPIX_I;
+                const int rr = g + 4 * j;
                 const float4 v = vv[j];
                 const floatx2 vl = {v.x, v.y}, vh = {v.z, v.w};
                 const floatx2 al = __builtin_elementwise_fma(vl, scl, shl), ah = __builtin_elementwise_fma(vh, sch, shh);
                 const floatx2 xl = __builtin_elementwise_fma(vl, isl, nml), xh = __builtin_elementwise_fma(vh, ish, nmh);
                 float4 m;
-                m.x = (ok && al.x > 0.f) ? 1.f : 0.f; m.y = (ok && al.y > 0.f) ? 1.f : 0.f;
-                m.z = (ok && ah.x > 0.f) ? 1.f : 0.f; m.w = (ok && ah.y > 0.f) ? 1.f : 0.f;
+                m.x = al.x > 0.f ? 1.f : 0.f; m.y = al.y > 0.f ? 1.f : 0.f;
+                m.z = ah.x > 0.f ? 1.f : 0.f; m.w = ah.y > 0.f ? 1.f : 0.f;
                 const floatx2 rl = floatx2{m.x, m.y} * xl, rh = floatx2{m.z, m.w} * xh;
                 *reinterpret_cast<float4*>(&xw[rr * SP + 4 * i]) = make_float4(rl.x, rl.y, rh.x, rh.y);
                 *reinterpret_cast<float4*>(&mw[rr * SP + 4 * i]) = m;
             }
-            if (rbk + 4 < RB) fetch_rows(img, rbk + 4);
-            else if (more) fetch_rows(img + gridDim.x, w);
+            if (q < 2) fetch_rows(img, q + 1);
+            else if (q == 2 && has13) fetch_rows(img, 3);
+            else if (more) fetch_rows(img + gridDim.x, 0);
             // ---- R += (m xhat)^T . D,  P += m^T . D   (contraction over the 16 pixels: 4 k-steps of 4)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const int px = 16 * rbk + 4 * s4 + g;
-                const bool ok = px < NPIX_I;
-                const int iy = px / HI, ix = px - iy * HI;
-                float b = dlb[ok ? (2 * iy + (i >> 2)) * PL + 2 * ix + (i & 3) : 0];   // tap i = ky*4 + kx
-                b = ok ? b : 0.f;
+                const float b = dlb[bidx[q][s4]];
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     dr[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[(4 * s4 + g) * SP + 16 * cb + i], b, dr[cb], 0, 0, 0);
