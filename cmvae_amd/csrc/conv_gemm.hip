@@ -2488,6 +2488,75 @@ static ConvGeom linear_geom(int rows, int K, int N, int a_pitch, int o_pitch) {
     return g;
 }
 
+// A Linear layer with many input blocks and few outputs (the data gradient of the causal layer's fc1: 2048 -> 64 over
+// 25 600 rows) has one column block and 100 row tiles: on the direct kernel 200 workgroups of one wave per SIMD walk 32
+// taps each between barriers (168 us, 40 TFLOP/s).  Split over the contraction instead: tap group y (<= 6 taps of
+// bf16 weight planes in LDS) of the weight-stationary kernel writes its partial product to part[y], and the groups are
+// added in fixed order (reproducible, no atomics): 104 + 12 us for the same launch, 3 tiles x 6 taps per workgroup at
+// ~5 us per tap step -- the 8 KB operand rows are read 256 bytes at a time with 64 KB in flight per CU (starting every
+// workgroup at another tap, so that all 32 column blocks are read at any moment, changed nothing: 104 vs 107 us).
+__global__ __launch_bounds__(512, 1) void conv_gemm_wstat_splitk_kernel(ConvGeom g, const float* __restrict__ A,
+                                                                        const float* __restrict__ Wt,
+                                                                        float* __restrict__ part, long part_stride) {
+    const int ngrp = gridDim.y, base = g.ntaps / ngrp, rem = g.ntaps - base * ngrp, y = blockIdx.y;
+    const int tap0 = y * base + (y < rem ? y : rem), nt = base + (y < rem ? 1 : 0);
+    wstat_body<0, false, 8, false, false, false, true>(g, A, Wt, nullptr, nullptr, nullptr, part + y * part_stride, nullptr,
+                                                        0, tap0, nt, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z,
+                                                        (int)blockIdx.x, (int)gridDim.x);
+}
+// out[r][c] = sum_y part[y][r][c] (y ascending), c < ncols (a multiple of 4)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ngrp, long part_stride,
+                                                            long n4, int ncols4, int o_pitch, float* __restrict__ out) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        float4 s = reinterpret_cast<const float4*>(part)[e];
+        for (int y = 1; y < ngrp; ++y) {
+            const float4 v = reinterpret_cast<const float4*>(part + y * part_stride)[e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const long r = e / ncols4;
+        *reinterpret_cast<float4*>(out + r * o_pitch + 4 * (e - r * ncols4)) = s;
+    }
+}
+static int splitk_groups(int rows, int ntaps, int ncb) {
+#if CMVAE_BF3_LINEAR
+    if (ntaps <= BF3_TAPS || rows < CMVAE_BF3_LINEAR) return 0;
+    const int ngrp = (ntaps + BF3_TAPS - 1) / BF3_TAPS;
+    // worth it while the direct kernel's (row tile, column block) workgroups leave the chip half empty
+    return (long)((rows + 127) / 128) * ncb <= 2L * compute_units() ? ngrp : 0;
+#else
+    return 0;
+#endif
+}
+static size_t splitk_workspace_bytes(int rows, int ntaps, int ncb) {
+    return align_up((size_t)splitk_groups(rows, ntaps, ncb) * rows * ncb * 64 * sizeof(float));
+}
+static int launch_gemm_splitk(const ConvGeom& g, const float* A, const float* Wt, int ncb, float* out, float* part,
+                              hipStream_t st) {
+    const int ngrp = splitk_groups(g.rows_total, g.ntaps, ncb);
+    const size_t lds = (size_t)((g.ntaps + ngrp - 1) / ngrp) * BF3_TAP_BYTES + 2 * 8 * 32 * sizeof(int) + 8 * 128 * sizeof(float);
+    static const bool opted = [] {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_wstat_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        (void)hipGetLastError();
+        return true;
+    }();
+    (void)opted;
+    ConvGeom gp = g;
+    gp.o_pitch = 64 * ncb;                                         // partials are dense [rows][64 ncb]
+    const long part_stride = (long)g.rows_total * gp.o_pitch;
+    const int ntiles = (g.rows_total + 255) / 256;
+    int nx = compute_units() / (ngrp * ncb);
+    if (nx < 1) nx = 1;
+    if (nx > ntiles) nx = ntiles;
+    hipLaunchKernelGGL(conv_gemm_wstat_splitk_kernel, dim3(nx, ngrp, ncb), dim3(512), lds, st, gp, A, Wt, part, part_stride);
+    if (int e = check_launch("conv_gemm_wstat_splitk_kernel")) return e;
+    const long n4 = part_stride / 4;
+    const int nb = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, part, ngrp, part_stride, n4, gp.o_pitch / 4,
+                       g.o_pitch, out);
+    return check_launch("splitk_reduce_kernel");
+}
+
 static int launch_gemm(const ConvGeom& g, const float* A, const float* Wt, const float* bias, int act, int ncb,
                        float* out, hipStream_t st, const float* mse_target = nullptr, int mse_M = 1, int mse_pitch = 0,
                        float* mse_part = nullptr) {
@@ -2601,7 +2670,7 @@ extern "C" int cmvae_linear_mse_fwd(const float* X, int x_pitch, int rows, int i
 
 extern "C" size_t cmvae_linear_bwd_workspace_bytes(int rows, int in_f, int out_f) {
     return cmvae_conv_wgrad_workspace_bytes(rows) + align_up((size_t)in_f * out_f * sizeof(float)) +
-           align_up((size_t)COLSUM_BLOCKS * out_f * sizeof(float));
+           align_up((size_t)COLSUM_BLOCKS * out_f * sizeof(float)) + splitk_workspace_bytes(rows, out_f / 64, in_f / 64);
 }
 
 extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, const float* dZ, int dz_pitch, int rows,
@@ -2626,7 +2695,11 @@ extern "C" int cmvae_linear_bwd(const float* X, int x_pitch, const float* W, con
     if (dX) {       // dX = dZ @ W: contraction over the out_f columns of dZ, weights transposed to [in][out]
         hipLaunchKernelGGL(transpose_kernel, dim3(in_f / 32, out_f / 32), dim3(256), 0, st, W, out_f, in_f, Wt2);
         if (int e = check_launch("transpose_kernel")) return e;
-        if (int e = launch_gemm(linear_geom(rows, out_f, in_f, dz_pitch, dx_pitch), dZ, Wt2, nullptr, 0, kin, dX, st))
+        if (splitk_groups(rows, kout, kin)) {
+            float* sk_part = (float*)((char*)cs_part + align_up((size_t)COLSUM_BLOCKS * out_f * sizeof(float)));
+            if (int e = launch_gemm_splitk(linear_geom(rows, out_f, in_f, dz_pitch, dx_pitch), dZ, Wt2, kin, dX, sk_part, st))
+                return e;
+        } else if (int e = launch_gemm(linear_geom(rows, out_f, in_f, dz_pitch, dx_pitch), dZ, Wt2, nullptr, 0, kin, dX, st))
             return e;
     }
     // dW[o][i] = sum_r dZ[r][o] X[r][i]: the operand with more 64-column blocks supplies the taps (4 per launch)

@@ -23,7 +23,10 @@ ACTS = {None: lambda v: v, 'relu': F.relu, 'elu': F.elu}
     (8200, 64, 512, 'elu'), (9001, 64, 1024, None),
     # >= 16 384 rows with in_features <= 384 (and the data gradient where out_features <= 384): weight planes resident
     # in LDS, products on the bf16 pipe (ragged last row tile; 1, 2, 4 and 6 taps)
-    (20001, 256, 256, 'elu'), (16400, 64, 2048, 'relu'), (17000, 384, 128, None), (20000, 128, 64, None)])
+    (20001, 256, 256, 'elu'), (16400, 64, 2048, 'relu'), (17000, 384, 128, None), (20000, 128, 64, None),
+    # data gradient with out_features > 384 over few column blocks: split over the contraction (6 and 3 tap groups of
+    # the bf16-pipe kernel, partial products added in fixed order; ragged last row tile, two column blocks)
+    (25601, 64, 2048, None), (20000, 128, 1024, 'elu')])
 def test_linear_fwd_bwd(rows, in_f, out_f, act):
     from cmvae_amd.linear import linear
     g = torch.Generator().manual_seed(rows + in_f)
