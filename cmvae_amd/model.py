@@ -131,7 +131,9 @@ class _GMVAEBase(nn.Module):
         """The EM of `_unsup_prior` issued on a second HIP stream, so that its chain of small dependent launches (33
         kernels of ~15 us on at most B*K workgroups) runs beside whatever the caller issues next on the current stream
         (the decoder's forward pass, which does not depend on it).  Returns a handle for `_unsup_prior_end`.  Same
-        kernels, same results; under HIP graph capture or with `em_side_stream = False` it runs in place."""
+        kernels, same results; under HIP graph capture or with `em_side_stream = False` it runs in place (as a parallel
+        branch of the feature models' captured step it was measured: 1.436 vs 1.436 ms, the graph runs its branches one
+        after the other)."""
         if not self.em_side_stream or not z.is_cuda or torch.cuda.is_current_stream_capturing():
             return self._unsup_prior(z, init_idx), None
         if init_idx is None:
