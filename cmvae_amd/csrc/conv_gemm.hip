@@ -344,6 +344,9 @@ constexpr int BF3_TAP_BYTES = 3 * 64 * 128;
 constexpr int BF3_TAPS = 6;                              // taps whose planes fit LDS at once
 // rows from which a pixel-major weight-stationary launch runs its products on the bf16 pipe (BF3): from about three
 // 256-row tiles per CU on, as for the 8-wave fp32 kernel
+#ifndef CMVAE_DGRAD_PARITY
+#define CMVAE_DGRAD_PARITY 1      // (0: a comparison build with the 16-tap data gradient's passes in tap order)
+#endif
 #ifndef CMVAE_BF3_LINEAR
 #define CMVAE_BF3_LINEAR 16384     // rows from which nn.Linear launches take the bf16 pipe (0: never; see launch_gemm)
 #endif
@@ -890,8 +893,33 @@ __device__ __forceinline__ void wstat_body(
     rows_of_tile(tile, ti, opix + w * 32);
     load_frag(t);
     floatx16 acc0 = {}, acc1 = {};
+    // ACCUM: what the output holds is requested at the tile's first tap, not in the epilogue (where the round trip of
+    // 32 loads per lane stood between the last MFMA and the stores of every tile: the layer-3 data gradient's adding
+    // passes 436 -> 365-389 us).  (The BatchNorm-backward epilogue's x requested under the last tap's MFMAs as well:
+    // 256 registers, 462 -> 452 us, nothing in the step time; it is loaded in the epilogue.)
+    float old0[ACCUM ? 16 : 1], old1[ACCUM ? 16 : 1];
+    bool old_here = false;                                         // uniform
     while (tile < ntiles) {
         float4 a[8];
+        if (ACCUM && t == first_tap(mask)) {
+            old_here = tile * BMT + 32 * w + 31 < g.rows_total && out_off32;
+            if (old_here) {
+                const int* op_w = opix + (par * NW + w) * 32;
+                const unsigned col_b = (unsigned)(nb * 64 + i) * 4u, pitch_b = (unsigned)g.o_pitch * 4u;
+                const char* ob = reinterpret_cast<const char*>(out);
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int4 ops = *reinterpret_cast<const int4*>(&op_w[8 * rq + 4 * h]);
+                    const int opv[4] = {ops.x, ops.y, ops.z, ops.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* p0 = (const float*)(ob + (__umul24((unsigned)opv[r], pitch_b) + col_b));
+                        old0[ACCUM ? 4 * rq + r : 0] = p0[0];
+                        old1[ACCUM ? 4 * rq + r : 0] = p0[32];
+                    }
+                }
+            }
+        }
         {
             const bool ok = ok_next;
 #pragma unroll
@@ -980,10 +1008,8 @@ __device__ __forceinline__ void wstat_body(
                     floatx2 v0 = floatx2{acc0[4 * rq + r], acc0[4 * rq + r + 1]} + bb0;
                     floatx2 v1 = floatx2{acc1[4 * rq + r], acc1[4 * rq + r + 1]} + bb1;
                     if (ACCUM) {
-                        const float* p0 = (const float*)(ob + (__umul24((unsigned)opv[r], pitch_b) + col_b));
-                        const float* p1 = (const float*)(ob + (__umul24((unsigned)opv[r + 1], pitch_b) + col_b));
-                        v0 += floatx2{p0[0], p1[0]};
-                        v1 += floatx2{p0[32], p1[32]};
+                        v0 += floatx2{old0[ACCUM ? 4 * rq + r : 0], old0[ACCUM ? 4 * rq + r + 1 : 0]};
+                        v1 += floatx2{old1[ACCUM ? 4 * rq + r : 0], old1[ACCUM ? 4 * rq + r + 1 : 0]};
                     }
                     if (BNB) {
                         const float* x0 = (const float*)(xb + (__umul24((unsigned)opv[r], pitch_b) + col_b));
@@ -2235,21 +2261,59 @@ extern "C" int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A
     const float* none = nullptr;
     // large pixel-major launches: products on the bf16 pipe (mfma_split6), at most BF3_TAPS taps' weight planes in LDS
     // per pass, later passes adding to the output; the last one carries the BatchNorm-backward sums
-    // (7 .. 9 taps fit LDS at once as fp32 and would take two passes here: layer 2's 9-tap data gradient ran 347 us in
-    // 4 + 5 taps on the bf16 pipe against 308 in one fp32 launch)
+    if (g.pm_nimg > 0 && g.rows_total >= bf3_min_rows() && g.ntaps <= 3 * BF3_TAPS) {
+        if (g.ntaps <= BF3_TAPS)
+            return launch_wstat<0, false, 8, true, true, false, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, 0, g.ntaps, st, bnb);
+        // More taps than fit LDS: passes over tap groups, the later ones adding to the output (a tile with no in-image
+        // tap in a pass adds zero from one masked tap: tile_info), the last one with the BatchNorm-backward sums.
+        // The passes are bound by HBM traffic (16 taps as 5 + 5 + 6 in tap order: 401 / 538 / 621 us for 2.0 / 2.65 /
+        // 3.3 GB, 5 TB/s each), and with stride 2 a tap reads gradient pixels of ONE (row, column) parity class: a pass
+        // whose taps mix classes reads most of the gradient tensor again.  Taps are therefore ordered by class and the
+        // passes cut at class boundaries where that fits: a 4 x 4 kernel = four passes of four taps, each reading
+        // its quarter of the gradient once (330 + 389 + 365 + 462 us; same-box step 11.14 -> 10.85 ms together with the
+        // earlier request of the output in adding passes); layer 2's 3 x 3 kernel = (odd, odd) + (odd, even) taps, then
+        // the other three: 139 + 182 us against 330 in one fp32 launch (in 4 + 5 taps of tap order, and with the
+        // output requested in the epilogue, it had lost: 347 us).
+        ConvGeom gp = g;
+        int cut[8], ncut = 0;                                     // pass p = taps cut[p] .. cut[p + 1] - 1 of gp
+        cut[0] = 0;
+        bool by_class = false;
+#if CMVAE_DGRAD_PARITY
+        if (g.sy == 2 && g.sx == 2) {
+            int order[32], cnt[4] = {0, 0, 0, 0}, n = 0;
+            for (int c = 3; c >= 0; --c)                          // (odd, odd) first: the largest class of a 3 x 3 kernel
+                for (int t = 0; t < g.ntaps; ++t)
+                    if (((g.dy[t] & 1) * 2 + (g.dx[t] & 1)) == c) { order[n++] = t; ++cnt[c]; }
+            by_class = cnt[0] <= BF3_TAPS && cnt[1] <= BF3_TAPS && cnt[2] <= BF3_TAPS && cnt[3] <= BF3_TAPS;
+            if (by_class) {
+                for (int t = 0; t < g.ntaps; ++t) {
+                    gp.dy[t] = g.dy[order[t]]; gp.dx[t] = g.dx[order[t]];
+                    gp.a_col[t] = g.a_col[order[t]]; gp.w_off[t] = g.w_off[order[t]];
+                }
+                int in_pass = 0, pos = 0;
+                for (int c = 3; c >= 0; --c) {
+                    if (cnt[c] == 0) continue;
+                    if (in_pass + cnt[c] > BF3_TAPS) { cut[++ncut] = pos; in_pass = 0; }
+                    in_pass += cnt[c]; pos += cnt[c];
+                }
+                cut[++ncut] = g.ntaps;
+            }
+        }
+#endif
+        if (!by_class) {
+            ncut = (g.ntaps + BF3_TAPS - 1) / BF3_TAPS;
+            for (int p = 1; p <= ncut; ++p) cut[p] = (int)((long)g.ntaps * p / ncut);
+        }
+        for (int p = 0; p < ncut - 1; ++p) {
+            const int t0 = cut[p], nt = cut[p + 1] - cut[p];
+            if (p == 0) { if (int e = launch_wstat<0, false, 8, true, false, false, true>(gp, A, Wt, none, none, none, out, nullptr, 0, 1, t0, nt, st)) return e; }
+            else if (int e = launch_wstat<0, false, 8, true, false, true, true>(gp, A, Wt, none, none, none, out, nullptr, 0, 1, t0, nt, st)) return e;
+        }
+        return launch_wstat<0, false, 8, true, true, true, true>(gp, A, Wt, none, none, none, out, sums_part, gx, 1, cut[ncut - 1], g.ntaps - cut[ncut - 1], st, bnb);
+    }
+    // (below the bf16 pipe's row count: 7 .. 9 taps fit LDS at once as fp32)
     if (g.pm_nimg > 0 && g.ntaps > BF3_TAPS && g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256)
         return launch_wstat<0, false, 8, true, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, 0, g.ntaps, st, bnb);
-    if (g.pm_nimg > 0 && g.rows_total >= bf3_min_rows() && g.ntaps <= 3 * BF3_TAPS) {
-        const int ngrp = (g.ntaps + BF3_TAPS - 1) / BF3_TAPS;
-        if (ngrp == 1)
-            return launch_wstat<0, false, 8, true, true, false, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, 0, g.ntaps, st, bnb);
-        // (a tile with no in-image tap in a pass adds zero from one masked tap: tile_info)
-        const int b1 = g.ntaps / ngrp, b2 = ngrp == 3 ? 2 * g.ntaps / 3 : b1;
-        if (int e = launch_wstat<0, false, 8, true, false, false, true>(g, A, Wt, none, none, none, out, nullptr, 0, 1, 0, b1, st)) return e;
-        if (ngrp == 3)
-            if (int e = launch_wstat<0, false, 8, true, false, true, true>(g, A, Wt, none, none, none, out, nullptr, 0, 1, b1, b2 - b1, st)) return e;
-        return launch_wstat<0, false, 8, true, true, true, true>(g, A, Wt, none, none, none, out, sums_part, gx, 1, b2, g.ntaps - b2, st, bnb);
-    }
     const dim3 grid(gx, 1);
     if (g.pm_nimg > 0)
         hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, true, true>), grid, dim3(256), 0, st, g, A, Wt, none, out, sums_part, none, 1, 0, bnb);
