@@ -252,9 +252,11 @@ def roofline_conv_gemm(step_fn):
             e1.record()
             grp = group_of(*args, **kw)
             if grp:
-                # kernel launches behind the call: a data gradient on the bf16 pipe runs as accumulating passes of at
-                # most six taps (rocprof counts those)
-                nk = -(-args[0].ntaps // 6) if (name in ('conv_gemm_bnbwd', 'conv_gemm') and grp == 'bf16') else 1
+                # kernel launches behind the call: more than six taps on the bf16 pipe run as accumulating passes
+                # (rocprof counts those)
+                nk = 1
+                if grp == 'bf16' and name in ('conv_gemm_bnbwd', 'conv_gemm'):
+                    nk = conv.bf16_pipe_passes('bnbwd' if name == 'conv_gemm_bnbwd' else 'gemm', args[0])
                 rec[grp].append((e0, e1, flops_of(*args, **kw), nk))
             return r
         return f

@@ -161,7 +161,7 @@ def on_bf16_pipe(kind, geoms):
     if kind == 'multi':
         return pm and rows >= bf16_pipe_min_rows()
     if kind == 'bnbwd':
-        return pm and rows >= bf16_pipe_min_rows() and (g0.ntaps <= 6 or 9 < g0.ntaps <= 18)
+        return pm and rows >= bf16_pipe_min_rows() and g0.ntaps <= 18
     if kind == 'wgrad_multi':
         def rows4(g):       # four taps: two operand rows x {unshifted, shifted by one column}
             if g.ntaps != 4 or g.sx != 1 or g.Wg != g.Wi:
@@ -173,6 +173,28 @@ def on_bf16_pipe(kind, geoms):
             return True
         return npix > 0 and (g0.rows_total // npix) % 32 == 0 and rows >= bf16_pipe_min_rows() and all(rows4(g) for g in gs)
     raise ValueError(kind)
+
+
+def bf16_pipe_passes(kind, g):
+    """Kernel launches behind one bf16-pipe call of `kind` ('gemm' / 'bnbwd', see on_bf16_pipe): at most six taps of
+    weight planes fit LDS, so more taps run as accumulating passes — cut at the boundaries of the stride-2 parity
+    classes of the taps where a data gradient has them (csrc/conv_gemm.hip, cmvae_conv_gemm_bnbwd)."""
+    if g.ntaps <= 6:
+        return 1
+    if kind == 'bnbwd' and g.sy == 2 and g.sx == 2:
+        cnt = [0, 0, 0, 0]
+        for t in range(g.ntaps):
+            cnt[(g.dy[t] & 1) * 2 + (g.dx[t] & 1)] += 1
+        if max(cnt) <= 6:
+            passes, in_pass = 1, 0
+            for c in (3, 2, 1, 0):
+                if cnt[c] == 0:
+                    continue
+                if in_pass + cnt[c] > 6:
+                    passes, in_pass = passes + 1, 0
+                in_pass += cnt[c]
+            return passes
+    return -(-g.ntaps // 6)
 
 
 def _wgrad_ws(rows, device):

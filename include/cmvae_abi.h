@@ -216,8 +216,9 @@ int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A, const flo
  * column sums {sum, sum of squares} over ALL geometries' rows.                                                  */
 int cmvae_conv_gemm_multi_grid(void);
 /* Rows from which cmvae_conv_gemm (7 .. 9 taps, act 0, one column block), the pixel-major launches of
- * cmvae_conv_gemm_multi and cmvae_conv_gemm_bnbwd (<= 6 or 10 .. 18 taps) and cmvae_conv_wgrad_multi (four-tap phases,
- * image count a multiple of 32) run their fp32 products on the bf16 matrix pipe: every
+ * cmvae_conv_gemm_multi and cmvae_conv_gemm_bnbwd (<= 18 taps; more than 6 as accumulating passes, cut at the taps'
+ * stride-2 parity classes) and cmvae_conv_wgrad_multi (four-tap phases, image count a multiple of 32) run their fp32
+ * products on the bf16 matrix pipe (cmvae_linear_fwd / cmvae_linear_bwd: launches of >= 16384 rows, see there): every
  * operand split exactly into three bf16 pieces, six v_mfma_*_bf16 products per fp32 product, fp32 accumulation — the
  * results are fp32 results (tests/test_gpu_conv.py: test_bf16_pipe_products_are_fp32_products).  No counterpart in the
  * reference (omniglot/module.py:50-58 calls torch's conv_transpose2d); a measurement aid for bench.py and tests.  */
@@ -246,7 +247,11 @@ int cmvae_conv_wgrad_multi(const cmvae_conv_geom* geoms, int ngeom, const float*
 /* ==== nn.Linear (+ReLU/ELU) on the gather-GEMM kernels: proj (omniglot/model.py:70-77, mimgnet/model.py:59-66),
  * the Set-Transformer projections fc_q/k/v/o and the (mu, logvar) head (omniglot/module.py:80-86, model.py:65-68),
  * CausalEncoder.fc1 (omniglot/module.py:148,181).  W [out_f,in_f] as torch stores it; features are multiples of
- * 64, at most 2048.  Y = act(X W^T + bias); act: 0 none, 1 ReLU, 2 ELU.                                       */
+ * 64, at most 2048.  Y = act(X W^T + bias); act: 0 none, 1 ReLU, 2 ELU.
+ * Launches of >= 16384 rows whose contraction has at most 384 columns run their fp32 products on the bf16 matrix
+ * pipe (see cmvae_conv_bf16_pipe_min_rows); a data gradient with a longer contraction over few column blocks (fc1:
+ * 2048 -> 64) is split over the contraction into tap groups whose partial products (in the workspace) are added in
+ * fixed order.  Results are fp32 results and reproducible run to run.                                          */
 int cmvae_linear_fwd(const float* X, int x_pitch, int rows, int in_f, int out_f, const float* W,
                      const float* bias, int act, float* Y, int y_pitch, void* stream);
 /* The last proj layer of the feature models fused with their Gaussian likelihood (mimgnet/model.py:59-66, 388-391):
