@@ -181,7 +181,8 @@ def test_bf16_pipe_products_are_fp32_products(device):
     bf16 pieces and six of the nine piece products are accumulated in fp32 (csrc/conv_gemm.hip: mfma_split6).  What
     is dropped is below 2^-24 of |a b|, fp32's own rounding, so the results must be as close to float64 as an fp32
     computation is.  Layer-3-shaped transposed conv (64 -> 64, k 4, stride 2) over 1024 images of 14 x 14 — forward
-    (802 816 rows), data gradient (200 704 rows, three accumulating passes) and weight gradient (32-image chunks) all
+    (802 816 rows), data gradient (200 704 rows, four accumulating passes of one tap parity class each) and weight
+    gradient (32-image chunks) all
     take that path — against float64 on the CPU, next to PyTorch's own fp32 results on the same GPU."""
     from cmvae_amd import conv
     n, Hi, k = 1024, 14, 4
@@ -236,8 +237,9 @@ def test_bf16_pipe_products_are_fp32_products(device):
 
 
 def test_dgrad_bn_sums_epilogue_weight_stationary_kernel(device):
-    """Layer-2 shape of the training step (9-tap data gradient, >= 196608 rows: the eight-wave weight-stationary
-    kernel): gradient equal to the plain launch, sums equal to the separate reduction pass."""
+    """Layer-2 shape of the training step (9-tap stride-2 data gradient, >= 196608 rows: two accumulating passes of
+    6 + 3 taps on the bf16 pipe, cut at the taps' parity classes): gradient equal to the plain launch, sums equal to the
+    separate reduction pass."""
     from cmvae_amd import conv, decoder
     n, Hi, k = 12304, 4, 3
     Ho = conv.convT_out(Hi, k)
@@ -252,8 +254,8 @@ def test_dgrad_bn_sums_epilogue_weight_stationary_kernel(device):
     conv.conv_gemm(gd, gy, wtd, want)
     got = torch.full_like(want, float('nan'))
     part = conv.conv_gemm_bnbwd(gd, gy, wtd, got, x, fold)
-    # (the launch with the sums runs its products on the bf16 pipe in two accumulating passes of 5 + 4 taps: the same
-    # sums to fp32 rounding)
+    # (both run their products on the bf16 pipe in two accumulating passes — the plain launch 5 + 4 taps in tap order,
+    # the one with the sums 6 + 3 by parity class: the same sums to fp32 rounding)
     assert rel_err(got, want) < 1e-6 and float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
     s_want = decoder.bn_relu_bwd_sums(got, x, fold, masked=False)
     s_got = decoder.colsum(part)
