@@ -106,3 +106,25 @@ def test_torch_ops_namespace_lists_every_leaf_op():
               conv.geom_linear(10, 128, 256)):
         lst = reg.geom_to_list(g)
         assert reg.geom_to_list(reg.geom_from_list(lst)) == lst
+
+
+def test_bf16_pipe_rules_restated_for_measurement_code():
+    """`conv.on_bf16_pipe` / `conv.bf16_pipe_passes` restate the launch rules of csrc/conv_gemm.hip for bench.py's
+    roofline line (host arithmetic only: no launch).  A 4 x 4 stride-2 data gradient has four tap parity classes of
+    four taps = four accumulating passes, a 3 x 3 one 4 + 2 + 2 + 1 = two passes (6 + 3), a 3 x 3 conv at stride 1 two
+    passes of tap order, at most six taps one launch."""
+    from cmvae_amd import conv
+    thr = conv.bf16_pipe_min_rows()
+    assert thr == 3 * 256 * 256
+    n = 1024
+    g4, _ = conv.geom_convT_dgrad(n, 14, 14, 4, pixel_major=True)
+    assert g4.ntaps == 16 and g4.rows_total >= thr
+    assert conv.on_bf16_pipe('bnbwd', [g4]) and conv.bf16_pipe_passes('bnbwd', g4) == 4
+    g3, _ = conv.geom_convT_dgrad(4 * n, 7, 7, 3, pixel_major=True)
+    assert g3.ntaps == 9 and conv.on_bf16_pipe('bnbwd', [g3]) and conv.bf16_pipe_passes('bnbwd', g3) == 2
+    gc = conv.geom_conv3x3(1280, 14, 14)
+    assert gc.ntaps == 9 and conv.on_bf16_pipe('gemm', [gc]) and conv.bf16_pipe_passes('gemm', gc) == 2
+    small, _ = conv.geom_convT_dgrad(64, 14, 14, 4, pixel_major=True)
+    assert not conv.on_bf16_pipe('bnbwd', [small])
+    ph, _ = conv.geom_convT_phase(n, 14, 14, 4, 0, 1, pixel_major=True)
+    assert ph.ntaps <= 6 and conv.bf16_pipe_passes('bnbwd', ph) == 1
