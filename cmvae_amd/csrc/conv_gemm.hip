@@ -16,7 +16,9 @@
 //   conv_gemm_wstat_kernel         all W_t of the launch resident in LDS, A from global memory, no barrier (<= 9 taps;
 //                                  _multi_: up to four geometries side by side = the phases of a transposed conv;
 //                                  ACCUM: a later pass over another tap range, adding to the output; BNB:
-//                                  BatchNorm-backward sums epilogue; BF3: products on the bf16 pipe, <= 6 taps)
+//                                  BatchNorm-backward sums epilogue; BF3: products on the bf16 pipe, <= 6 taps;
+//                                  _splitk_: tap groups of one Linear data gradient side by side, partial products
+//                                  added by splitk_reduce_kernel)
 // The weight-gradient kernels contract over r instead (conv_wgrad_stream_kernel: fragments straight from global
 // memory on v_mfma_f32_16x16x4_f32; conv_wgrad_bf3_multi_kernel: the same on the bf16 pipe for four-tap phases;
 // conv_wgrad_kernel: LDS-staged, any shape).
@@ -1198,9 +1200,9 @@ static int dispatch_wstat(const ConvGeom& g, const float* A, const float* Wt, co
     if (g.ntaps <= WSTAT_TAPS8 && g.rows_total >= 3 * 256 * 256) {
         // 7 .. 9 taps (the encoder's 3 x 3 convs and their data gradients) on the bf16 pipe (mfma_split6): two passes of at
         // most six taps of weight planes, the second adding to the first one's output and carrying the bias and the
-        // statistics.  Same-box A/B of the Omniglot 20-way step: 11.41 / 11.33 -> 11.27 / 11.21 ms (the output is 64 MB
-        // there; layer 2's 9-tap data gradient, whose output is 481 MB, loses by the read-modify-write and stays on the
-        // fp32 MFMA: cmvae_conv_gemm_bnbwd).
+        // statistics.  Same-box A/B of the Omniglot 20-way step: 11.41 / 11.33 -> 11.27 / 11.21 ms.  (Stride-2 data
+        // gradients with the BatchNorm-backward sums go through cmvae_conv_gemm_bnbwd, which cuts its passes at the taps'
+        // parity classes.)
         if (ACT == 0 && n_col_blocks == 1 && g.ntaps > BF3_TAPS && g.rows_total >= bf3_min_rows()) {
             const int t1 = (g.ntaps + 1) / 2;
             if (int e = launch_wstat<0, HAS_T, 8, PM, false, false, true>(g, A, Wt, nullptr, a_scale, a_shift, out, nullptr, 0,
