@@ -289,11 +289,11 @@ def test_bn_finalize_from_partials_equals_two_step_path(device, nblk):
         assert rel_err(a, b) < 1e-5
 
 
-def test_dgrad_bn_sums_sixteen_taps_in_two_accumulating_launches(device):
-    """Layer-3 shape of the training step (16-tap data gradient over >= 196608 rows): three weight-stationary launches
-    of 5 + 5 + 6 taps on the bf16 pipe, the later ones adding to the output.  The partial sums are added in another
-    order than the single accumulator chain of the direct kernel: equal to rounding; the sums equal the separate
-    reduction."""
+def test_dgrad_bn_sums_sixteen_taps_in_accumulating_passes(device):
+    """Layer-3 shape of the training step (16-tap stride-2 data gradient over >= 196608 rows, image count not a multiple
+    of the 256-row tile): four weight-stationary launches on the bf16 pipe, one per parity class of the taps, the later
+    ones adding to the output.  The partial sums are added in another order than the single accumulator chain of the
+    direct kernel: equal to rounding; the sums equal the separate reduction."""
     from cmvae_amd import conv, decoder
     n, Hi, k = 4112, 7, 4
     Ho = conv.convT_out(Hi, k)
