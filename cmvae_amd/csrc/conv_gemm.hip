@@ -1182,6 +1182,43 @@ static int launch_wstat(const ConvGeom& g, const float* A, const float* Wt, cons
     return check_launch("conv_gemm_wstat_kernel");
 }
 
+// Tap groups of a launch with more taps than fit LDS as bf16 planes (BF3_TAPS): gp = g with its taps ordered by
+// stride-2 parity class where the geometry has them (a pass then reads its part of a gathered tensor once), cut[p] ..
+// cut[p + 1] - 1 = the taps of pass p; returns the number of passes (<= 4).
+static int bf3_pass_plan(const ConvGeom& g, ConvGeom& gp, int cut[8]) {
+    gp = g;
+    int ncut = 0;
+    cut[0] = 0;
+    bool by_class = false;
+#if CMVAE_DGRAD_PARITY
+    if (g.sy == 2 && g.sx == 2) {
+        int order[32], cnt[4] = {0, 0, 0, 0}, n = 0;
+        for (int c = 3; c >= 0; --c)                              // (odd, odd) first: the largest class of a 3 x 3 kernel
+            for (int t = 0; t < g.ntaps; ++t)
+                if (((g.dy[t] & 1) * 2 + (g.dx[t] & 1)) == c) { order[n++] = t; ++cnt[c]; }
+        by_class = cnt[0] <= BF3_TAPS && cnt[1] <= BF3_TAPS && cnt[2] <= BF3_TAPS && cnt[3] <= BF3_TAPS;
+        if (by_class) {
+            for (int t = 0; t < g.ntaps; ++t) {
+                gp.dy[t] = g.dy[order[t]]; gp.dx[t] = g.dx[order[t]];
+                gp.a_col[t] = g.a_col[order[t]]; gp.w_off[t] = g.w_off[order[t]];
+            }
+            int in_pass = 0, pos = 0;
+            for (int c = 3; c >= 0; --c) {
+                if (cnt[c] == 0) continue;
+                if (in_pass + cnt[c] > BF3_TAPS) { cut[++ncut] = pos; in_pass = 0; }
+                in_pass += cnt[c]; pos += cnt[c];
+            }
+            cut[++ncut] = g.ntaps;
+        }
+    }
+#endif
+    if (!by_class) {
+        ncut = (g.ntaps + BF3_TAPS - 1) / BF3_TAPS;
+        for (int p = 1; p <= ncut; ++p) cut[p] = (int)((long)g.ntaps * p / ncut);
+    }
+    return ncut;
+}
+
 template <int ACT, bool HAS_T, bool PM>
 static int dispatch_wstat(const ConvGeom& g, const float* A, const float* Wt, const float* bias, const float* a_scale,
                           const float* a_shift, float* out, float* stats_part, int stats_rows, int n_col_blocks,
@@ -2222,6 +2259,8 @@ extern "C" int cmvae_conv_gemm(const cmvae_conv_geom* geom, const float* A, cons
 #undef CMVAE_WSTAT
         if (handled || e) return e;
     }
+    // (10 .. 18 taps, pixel-major, no fold — the decoder's first 4 x 4 layer's data gradient, 16 taps over 153 600 rows —
+    // as bf16-pipe passes like cmvae_conv_gemm_bnbwd's: 33 + 38 + 40 + 35 us against 132 us here; not kept)
     if (!a_scale) {          // no folded BatchNorm: operand fragments straight from global memory
         if (pm) hipLaunchKernelGGL((conv_gemm_direct_kernel<0, false, true>), grid, dim3(256), 0, st, g, A, Wt, bias, out, stats_part, (const float*)nullptr, 1, 0);
         else switch (act) {
@@ -2276,36 +2315,9 @@ extern "C" int cmvae_conv_gemm_bnbwd(const cmvae_conv_geom* geom, const float* A
         // earlier request of the output in adding passes); layer 2's 3 x 3 kernel = (odd, odd) + (odd, even) taps, then
         // the other three: 139 + 182 us against 330 in one fp32 launch (in 4 + 5 taps of tap order, and with the
         // output requested in the epilogue, it had lost: 347 us).
-        ConvGeom gp = g;
-        int cut[8], ncut = 0;                                     // pass p = taps cut[p] .. cut[p + 1] - 1 of gp
-        cut[0] = 0;
-        bool by_class = false;
-#if CMVAE_DGRAD_PARITY
-        if (g.sy == 2 && g.sx == 2) {
-            int order[32], cnt[4] = {0, 0, 0, 0}, n = 0;
-            for (int c = 3; c >= 0; --c)                          // (odd, odd) first: the largest class of a 3 x 3 kernel
-                for (int t = 0; t < g.ntaps; ++t)
-                    if (((g.dy[t] & 1) * 2 + (g.dx[t] & 1)) == c) { order[n++] = t; ++cnt[c]; }
-            by_class = cnt[0] <= BF3_TAPS && cnt[1] <= BF3_TAPS && cnt[2] <= BF3_TAPS && cnt[3] <= BF3_TAPS;
-            if (by_class) {
-                for (int t = 0; t < g.ntaps; ++t) {
-                    gp.dy[t] = g.dy[order[t]]; gp.dx[t] = g.dx[order[t]];
-                    gp.a_col[t] = g.a_col[order[t]]; gp.w_off[t] = g.w_off[order[t]];
-                }
-                int in_pass = 0, pos = 0;
-                for (int c = 3; c >= 0; --c) {
-                    if (cnt[c] == 0) continue;
-                    if (in_pass + cnt[c] > BF3_TAPS) { cut[++ncut] = pos; in_pass = 0; }
-                    in_pass += cnt[c]; pos += cnt[c];
-                }
-                cut[++ncut] = g.ntaps;
-            }
-        }
-#endif
-        if (!by_class) {
-            ncut = (g.ntaps + BF3_TAPS - 1) / BF3_TAPS;
-            for (int p = 1; p <= ncut; ++p) cut[p] = (int)((long)g.ntaps * p / ncut);
-        }
+        ConvGeom gp;
+        int cut[8];                                               // pass p = taps cut[p] .. cut[p + 1] - 1 of gp
+        const int ncut = bf3_pass_plan(g, gp, cut);
         for (int p = 0; p < ncut - 1; ++p) {
             const int t0 = cut[p], nt = cut[p + 1] - cut[p];
             if (p == 0) { if (int e = launch_wstat<0, false, 8, true, false, false, true>(gp, A, Wt, none, none, none, out, nullptr, 0, 1, t0, nt, st)) return e; }
