@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float* __
     const float4 mu = reinterpret_cast<const float4*>(mean)[q], is = reinterpret_cast<const float4*>(invstd)[q];
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     for (long r = (long)blockIdx.x * 16 + rb; r < rows; r += (long)gridDim.x * 16) {
-        float4 g = reinterpret_cast<const float4*>(d_a + r * C)[q];
-        const float4 v = reinterpret_cast<const float4*>(y + r * C)[q];
+        float4 g = load_once(d_a + r * C + 4 * q);
+        const float4 v = load_once(y + r * C + 4 * q);
         if (!masked) {
             g.x = fmaf(v.x, sc.x, sh.x) > 0.f ? g.x : 0.f;
             g.y = fmaf(v.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float* __r
         o.y = sc.y * (g.y - a1.y - (v.y - mu.y) * is.y * a2.y);
         o.z = sc.z * (g.z - a1.z - (v.z - mu.z) * is.z * a2.z);
         o.w = sc.w * (g.w - a1.w - (v.w - mu.w) * is.w * a2.w);
-        reinterpret_cast<float4*>(dy + r * C)[q] = o;
+        store_once(dy + r * C + 4 * q, o);
     }
 }
 
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 3) void dec_out_bwd_kernel(con
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int px = 16 * rbk + g + 4 * j;
-            vv[j] = *reinterpret_cast<const float4*>(yi + (px < NPIX_I ? px : NPIX_I - 1) * C + 4 * i);
+            vv[j] = load_once(yi + (px < NPIX_I ? px : NPIX_I - 1) * C + 4 * i);
         }
     };
     if ((int)blockIdx.x < nimg) {
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 3) void dec_out_bwd_kernel(con
                 if (MODE == 1) {
                     const floatx2 rl = (__builtin_elementwise_fma(xl, nk2l, ol) - k1l) * scl;
                     const floatx2 rh = (__builtin_elementwise_fma(xh, nk2h, oh) - k1h) * sch;
-                    if (ok) *reinterpret_cast<float4*>(di + px * C + 4 * i) = make_float4(rl.x, rl.y, rh.x, rh.y);
+                    if (ok) store_once(di + px * C + 4 * i, make_float4(rl.x, rl.y, rh.x, rh.y));
                     continue;
                 }
                 if (ok && dybn) *reinterpret_cast<float4*>(di + px * C + 4 * i) = o;

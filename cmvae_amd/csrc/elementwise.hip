@@ -302,7 +302,7 @@ template <int ACT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__ dY, const float4* __restrict__ Y,
                                                       long n4, float4* __restrict__ dZ) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-        const float4 g = dY[e], y = Y[e];
+        const float4 g = load_once(reinterpret_cast<const float*>(dY + e)), y = load_once(reinterpret_cast<const float*>(Y + e));
         float4 o;
         if (ACT == 1) {
             o.x = y.x > 0.f ? g.x : 0.f; o.y = y.y > 0.f ? g.y : 0.f;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__
             o.x = y.x > 0.f ? g.x : g.x * (y.x + 1.f); o.y = y.y > 0.f ? g.y : g.y * (y.y + 1.f);
             o.z = y.z > 0.f ? g.z : g.z * (y.z + 1.f); o.w = y.w > 0.f ? g.w : g.w * (y.w + 1.f);
         }
-        dZ[e] = o;
+        store_once(reinterpret_cast<float*>(dZ + e), o);
     }
 }
 
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void causal_lc_fwd_kernel(const float* __restr
     const int l8 = threadIdx.x & 7;
     for (long it = (long)blockIdx.x * 32 + (threadIdx.x >> 3); it < items; it += (long)gridDim.x * 32) {
         const int j = (int)(it & 63);
-        const float4 h = *reinterpret_cast<const float4*>(hid + it * M1 + 4 * l8);
+        const float4 h = load_once(hid + it * M1 + 4 * l8);
         const float4 w = *reinterpret_cast<const float4*>(w2 + j * M1 + 4 * l8);
         float s = fmaf(h.x, w.x, fmaf(h.y, w.y, fmaf(h.z, w.z, h.w * w.w)));
         s += __shfl_xor(s, 1);
@@ -375,13 +375,13 @@ __global__ __launch_bounds__(512) void causal_lc_bwd_kernel(const float* __restr
     float db = 0.f;
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         const float g = -d_eps[(long)r * D + j];
-        const float4 h = *reinterpret_cast<const float4*>(hid + (long)r * HID + 4 * t);
+        const float4 h = load_once(hid + (long)r * HID + 4 * t);
         float4 o;
         o.x = g * w.x * (h.x > 0.f ? 1.f : h.x + 1.f);
         o.y = g * w.y * (h.y > 0.f ? 1.f : h.y + 1.f);
         o.z = g * w.z * (h.z > 0.f ? 1.f : h.z + 1.f);
         o.w = g * w.w * (h.w > 0.f ? 1.f : h.w + 1.f);
-        *reinterpret_cast<float4*>(d_pre + (long)r * HID + 4 * t) = o;
+        store_once(d_pre + (long)r * HID + 4 * t, o);
         dw.x = fmaf(g, h.x, dw.x); dw.y = fmaf(g, h.y, dw.y);
         dw.z = fmaf(g, h.z, dw.z); dw.w = fmaf(g, h.w, dw.w);
         d1.x += o.x; d1.y += o.y; d1.z += o.z; d1.w += o.w;
