@@ -14,6 +14,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef CMVAE_EM_SERIAL_FIN
+#define CMVAE_EM_SERIAL_FIN 0
+#endif
 namespace cmvae {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -592,7 +595,15 @@ __global__ __launch_bounds__(1024) void em_finalize_kernel(FinArgs a) {
     __shared__ __align__(16) float es[D];
     __shared__ float nall[32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int k = blockIdx.x, b = blockIdx.y, K = a.K;
+    const int b = blockIdx.y, K = a.K;
+#if CMVAE_EM_SERIAL_FIN      // timing only: ONE workgroup per episode finalizes its K components one after the
+                             // other — what the last-arriving workgroup of a single-launch EM iteration would have to do
+    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    __syncthreads();
+#else
+    const int k = blockIdx.x;
+    {
+#endif
     float S1 = 0.f, S2 = 0.f, Nk = 0.f, pi_k = 1.f / K;
     float uN = 0.f;
     // operands that do not depend on the reduction are requested first: their latency hides behind it
@@ -728,6 +739,7 @@ __global__ __launch_bounds__(1024) void em_finalize_kernel(FinArgs a) {
             a.tau[b * K + k] = a.tau_new;
             a.logw[b * K + k] = logf(pi_k) + p;
         }
+    }
     }
 }
 
@@ -1010,7 +1022,7 @@ static int unsup_prior_run(const float* z, int B, int N, int K, const int64_t* i
     f.z = z; f.init_idx = init_idx; f.N = N; f.K = K; f.fix_pi = fix_pi; f.semi = 0; f.init = 1;
     f.minv = w.minv0; f.minv_stride = 0; f.tau_new = 1.0f; f.c = *c;
     f.pi = pi; f.mu = mu; f.logvar = nullptr; f.tau = tau; f.logw = logw;
-    hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(CMVAE_EM_SERIAL_FIN ? 1 : K, B), dim3(1024), 0, st, f);
     if (int e = check_launch("em_finalize_kernel(init)")) return e;
     PassArgs p{};
     p.z = z; p.mu = mu; p.logw = logw; p.part_N = w.part_N; p.part_S1 = w.part_S1;
@@ -1019,7 +1031,7 @@ static int unsup_prior_run(const float* z, int B, int N, int K, const int64_t* i
     f.minv = minv_loop; f.tau_new = gamma1;
     for (int it = 0; it < iters; ++it) {
         if (int e = launch_pass(p, B, st)) return e;
-        hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
+        hipLaunchKernelGGL(em_finalize_kernel, dim3(CMVAE_EM_SERIAL_FIN ? 1 : K, B), dim3(1024), 0, st, f);
         if (int e = check_launch("em_finalize_kernel")) return e;
     }
     return 0;
@@ -1140,7 +1152,7 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
     f.K = K; f.fix_pi = 1; f.semi = 1; f.init = 1; f.sN = w.sN; f.sS1 = w.sS1; f.sS2 = w.sS2;
     f.minv = w.minv0; f.minv_stride = 0; f.tau_new = 1.0f; f.c = *c;
     f.pi = pi; f.mu = mu; f.logvar = logvar; f.tau = tau; f.logw = logw;
-    hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(CMVAE_EM_SERIAL_FIN ? 1 : K, B), dim3(1024), 0, st, f);
     if (int e = check_launch("em_finalize_kernel(semi init)")) return e;
     PassArgs p{};
     p.z = uz; p.mu = mu; p.logw = logw; p.part_N = w.part_N; p.part_S1 = w.part_S1; p.part_S2 = w.part_S2;
@@ -1160,7 +1172,7 @@ extern "C" int cmvae_semi_prior(const float* uz, const float* sz, const int64_t*
             if (int e = check_launch("gram_inverse_kernel")) return e;
         }
         if (int e = launch_pass(p, B, st)) return e;
-        hipLaunchKernelGGL(em_finalize_kernel, dim3(K, B), dim3(1024), 0, st, f);
+        hipLaunchKernelGGL(em_finalize_kernel, dim3(CMVAE_EM_SERIAL_FIN ? 1 : K, B), dim3(1024), 0, st, f);
         if (int e = check_launch("em_finalize_kernel")) return e;
     }
     return 0;
